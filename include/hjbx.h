@@ -1,0 +1,215 @@
+/*
+ * hjbx.h -- C ABI of libhjbx.so: MI355X (gfx950) batched control-affine rollouts + HJB residuals.
+ *
+ * This is the drop-in boundary for the hot path of HaoxiangYou/Q_Learning_with_HJB (SURVEY.md
+ * section 8b).  The reference has no FFI: its "operator API" is two Python base classes
+ * (dynamics/dynamics_basic.py:7-122 `Dynamics`, controller/controller_basic.py:1-5 `Controller`)
+ * plus the math inside controller/vhjb.py.  Each entry point below names the reference statement(s)
+ * it replaces; q_learning_with_hjb_amd/_abi.py is the ctypes binding a maintainer would add
+ * (INTEGRATION.md shows the reference-side patch).
+ *
+ * Conventions
+ *  - Every array argument is a raw DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) to a
+ *    contiguous row-major buffer; `hjbx_task` / `hjbx_controller` / `hjbx_mlp` descriptors are
+ *    HOST structs read during the call (copied into kernel arguments).  No torch types cross.
+ *  - State batches are (B, n) row-major ("batch_size, state_dim": dynamics_basic.py:58-60),
+ *    controls (B, m), f2 (B, n, m).  Trajectory slabs are time-major: (T+1, B, n).
+ *  - `_f32` entry points take float buffers, `_f64` double buffers.  Descriptor fields are double
+ *    and are rounded to float once per call for `_f32`.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are enqueued and
+ *    the call returns; nothing here synchronises, allocates device memory or copies to the host.
+ *  - Return value: HJBX_OK (0) or a negative hjbx_status.  hjbx_last_error() gives the message of
+ *    the calling thread's last failure.  No C++ exception crosses this boundary.
+ *  - Handles are immutable after creation and may be shared between host threads.
+ */
+#ifndef HJBX_H
+#define HJBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HJBX_VERSION 100 /* major*100 + minor */
+#define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
+#define HJBX_MAX_M 3     /* largest control dimension */
+
+typedef enum hjbx_status {
+    HJBX_OK = 0,
+    HJBX_EINVAL = -1,       /* bad argument (NULL pointer, bad size, bad enum) */
+    HJBX_EUNSUPPORTED = -2, /* valid request this build has no kernel for */
+    HJBX_EHIP = -3,         /* HIP runtime error (message carries hipGetErrorString) */
+    HJBX_ENODEVICE = -4     /* no usable gfx950 device */
+} hjbx_status;
+
+/* Which dynamics class of the reference the handle stands for. */
+typedef enum hjbx_system_kind {
+    HJBX_SYS_LINEAR = 0,    /* dynamics/linear.py:7-22      params = A (n*n row-major) then B (n*m) */
+    HJBX_SYS_CARTPOLE = 1,  /* dynamics/cartpole.py:10-64   params = mc, mp, l, g                    */
+    HJBX_SYS_ACROBOT = 2,   /* dynamics/acrobot.py:19-81    params = m1, m2, l1, l2, I1, I2, g       */
+    HJBX_SYS_QUAD2D = 3,    /* dynamics/quadrotors.py:9-70  params = m, r, I, g                      */
+    HJBX_SYS_NEARHOVER = 4  /* dynamics/quadrotors.py:102-170 params = g, m, kT, n0                  */
+} hjbx_system_kind;
+
+typedef enum hjbx_integrator {
+    HJBX_EULER = 0, /* x' = wrap(x + dt*xdot): the reference's integrator, dynamics_basic.py:120 (parity mode) */
+    HJBX_RK4 = 1    /* classic RK4 with zero-order-hold control, wrap applied once at the end (new mode)         */
+} hjbx_integrator;
+
+typedef enum hjbx_residual_mode {
+    HJBX_RESIDUAL_NORMALISED = 0, /* |gradV.xdot/(l+eps) + 1| (1-done): controller/vhjb.py:233       */
+    HJBX_RESIDUAL_RAW = 1         /* |gradV.xdot + l| (1-done): examples/cartpole_balancing.ipynb cell 11 */
+} hjbx_residual_mode;
+
+typedef enum hjbx_controller_kind {
+    HJBX_CTRL_LINEAR_FEEDBACK = 0, /* u = clip(-K e + uf): controller/lqr.py:25-26, quadrotors_model_based_controller.py:36-38, 73-75 */
+    HJBX_CTRL_CARTPOLE_ENERGY = 1, /* controller/cartpole_energy_shaping.py:65-110 */
+    HJBX_CTRL_ACROBOT_ENERGY = 2   /* controller/acrobot_energy_shaping.py:74-121  */
+} hjbx_controller_kind;
+
+/* rollout flags */
+#define HJBX_ROLLOUT_TERMINATE 1u /* stop an environment when wrap(x-xf) leaves [obs_min, obs_max] (vhjb.py:176-181) */
+
+typedef struct hjbx_system hjbx_system; /* opaque */
+
+/* Task = the cost / target / observation-box part of VHJBControllerConfig
+ * (configs/controller/vhjb_controller_config.py:47-55) plus P from vhjb.py:156-160. Row-major,
+ * only the leading n*n / m*m / n / m entries are read. */
+typedef struct hjbx_task {
+    double Q[HJBX_MAX_N * HJBX_MAX_N];
+    double R[HJBX_MAX_M * HJBX_MAX_M];
+    double Rinv[HJBX_MAX_M * HJBX_MAX_M];
+    double P[HJBX_MAX_N * HJBX_MAX_N]; /* terminal cost e'Pe, vhjb.py:167-169 */
+    double xf[HJBX_MAX_N];
+    double uf[HJBX_MAX_M];
+    double obs_min[HJBX_MAX_N]; /* bounds on the error coordinates wrap(x-xf), strict compares */
+    double obs_max[HJBX_MAX_N];
+    double eps;                 /* VHJBControllerConfig.epsilon */
+} hjbx_task;
+
+/* Closed-form feedback laws. */
+typedef struct hjbx_controller {
+    int32_t kind;       /* hjbx_controller_kind */
+    int32_t wrap_error; /* LINEAR_FEEDBACK: e = wrap_error ? wrap(x-xf) : x-xf */
+    double K[HJBX_MAX_M * HJBX_MAX_N]; /* (m, n) row-major state-feedback gain */
+    double xf[HJBX_MAX_N];
+    double uf[HJBX_MAX_M];
+    double P[HJBX_MAX_N * HJBX_MAX_N]; /* ACROBOT_ENERGY: LQR region is e'Pe < eps_region */
+    double Kes[3];      /* energy-shaping gains (cartpole [4,4,10], acrobot [1,2,1]) */
+    double eps_energy;  /* CARTPOLE_ENERGY: |E-E(xf)| < eps_energy ... */
+    double eps_state;   /* ... and ||(dtheta_err, dtheta_dot)|| < eps_state selects the LQR branch */
+    double eps_region;  /* ACROBOT_ENERGY */
+} hjbx_controller;
+
+/* Value network of controller/vhjb.py:17-60 (no bias, BatchNorm off): device weight pointers,
+ * Flax Dense layout (in, out) row-major, y = x @ W. */
+typedef struct hjbx_mlp {
+    const void* W1; /* (n,  h1) */
+    const void* W2; /* (h1, h2) */
+    const void* W3; /* (h2, h3) */
+    int32_t h1, h2, h3;
+    int32_t _pad;
+    double mean[HJBX_MAX_N]; /* normalization_mean */
+    double std[HJBX_MAX_N];  /* normalization_std  */
+    double xf[HJBX_MAX_N];
+    double eps_scalar;       /* epsilon_scalar */
+} hjbx_mlp;
+
+/* ---- library / handles --------------------------------------------------------------------- */
+int hjbx_version(void);
+/* Copies the calling thread's last error message (NUL terminated) into buf; returns its length. */
+size_t hjbx_last_error(char* buf, size_t buflen);
+/* Number of visible HIP devices whose arch is gfx950 (0 when there is none / no driver). */
+int hjbx_device_count(void);
+
+/* Replaces Dynamics.__init__ + subclass __init__ (dynamics_basic.py:17-26 etc.). */
+int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, const double* umax,
+                       const double* params, int n_params, hjbx_system** out);
+void hjbx_system_destroy(hjbx_system* sys);
+/* Dynamics.get_dimension, dynamics_basic.py:31-36 */
+int hjbx_dims(const hjbx_system* sys, int* n, int* m);
+/* bytes of scratch the reducing entry points need (hjb_residual, termination_residual) */
+size_t hjbx_reduce_workspace_bytes(void);
+
+#define HJBX_DECLARE(T, SFX)                                                                          \
+    /* Dynamics.get_control_affine_matrix (dynamics_basic.py:64-94, linear.py:20-22,                 \
+       quadrotors.py:17-46, 118-149): f1 (B,n), f2 (B,n,m). */                                       \
+    int hjbx_affine_##SFX(const hjbx_system* sys, const T* x, T* f1, T* f2, int64_t B, void* stream); \
+    /* Dynamics.states_wrap (cartpole.py:52-64, acrobot.py:72-81, quadrotors.py:48-70, 151-170);     \
+       out may alias x (the NumPy branch of the reference wraps in place). */                        \
+    int hjbx_wrap_##SFX(const hjbx_system* sys, const T* x, T* out, int64_t B, void* stream);         \
+    /* Dynamics.dynamics_step (dynamics_basic.py:96-105): xdot = f1 + f2 u, u NOT clipped. */         \
+    int hjbx_dynamics_step_##SFX(const hjbx_system* sys, const T* x, const T* u, T* xdot, int64_t B,  \
+                                 void* stream);                                                       \
+    /* Dynamics.simulate (dynamics_basic.py:107-122): u clipped to [umin,umax], one integrator step, \
+       wrap.  x_next may alias x. */                                                                  \
+    int hjbx_simulate_##SFX(const hjbx_system* sys, int integrator, const T* x, const T* u,           \
+                            T* x_next, int64_t B, void* stream);                                      \
+    /* Dynamics.get_initial_state (dynamics_basic.py:28-29) for B environments:                      \
+       x0 = wrap(-x0_std + 2 x0_std * u01 + x0_mean); u01 (B,n) are caller-supplied uniforms so the   \
+       RNG stays with the caller (the reference uses NumPy's global MT19937). */                      \
+    int hjbx_initial_state_##SFX(const hjbx_system* sys, const double* x0_mean, const double* x0_std, \
+                                 const T* u01, T* x0, int64_t B, void* stream);                       \
+    /* VHJBController.running_cost (vhjb.py:162-165): cost (B,) = e'Qe + (u-uf)'R(u-uf). */           \
+    int hjbx_running_cost_##SFX(const hjbx_system* sys, const hjbx_task* task, const T* x,            \
+                                const T* u, T* cost, int64_t B, void* stream);                        \
+    /* VHJBController.termination_cost (vhjb.py:167-169): cost (B,) = e'Pe. */                        \
+    int hjbx_termination_cost_##SFX(const hjbx_system* sys, const hjbx_task* task, const T* x,        \
+                                    T* cost, int64_t B, void* stream);                                \
+    /* Control law of get_control_efforts_with_additional_term (vhjb.py:218-220):                    \
+       u = clip(-Rinv f2' gradV / 2 + uf, umin, umax). */                                             \
+    int hjbx_control_from_grad_##SFX(const hjbx_system* sys, const hjbx_task* task, const T* x,       \
+                                     const T* gradV, T* u, int64_t B, void* stream);                  \
+    /* hjb_loss body (vhjb.py:227-241) forward + analytic d(loss_i)/d(gradV).           \
+       done (B,) is the 0/1 mask as T.  loss_i (B,) and dloss_dgrad (B,n) may be NULL.                \
+       sums[0..2] = {sum loss_i, sum (1-done), sum done}, reduced deterministically through the       \
+       caller's workspace (>= hjbx_reduce_workspace_bytes()); sums may be NULL. */                    \
+    int hjbx_hjb_residual_##SFX(const hjbx_system* sys, const hjbx_task* task, int mode, const T* x,  \
+                                const T* gradV, const T* done, T* loss_i, T* dloss_dgrad, T* sums,    \
+                                void* workspace, int64_t B, void* stream);                            \
+    /* termination_loss body (vhjb.py:243-253): loss_i = |V/(cost+eps) - 1| done,                    \
+       dloss_dV = sign(.) done/(cost+eps); sums as above. */                                          \
+    int hjbx_termination_residual_##SFX(double eps, const T* V, const T* cost, const T* done,         \
+                                        T* loss_i, T* dloss_dV, T* sums, void* workspace, int64_t B,  \
+                                        void* stream);                                                \
+    /* One iteration of rollout_trajectory's loop (vhjb.py:175-191) for B environments, given the    \
+       value gradient of the current states.  step t in [0,T]: environments with done_step<0 are     \
+       live.  A live env outside the observation box (or t==T) emits (cost=e'Pe, done=1), latches    \
+       done_step=t and holds its state; otherwise u from gradV, cost=l(x,u)*dt, done=0, x_next=       \
+       simulate(x,u).  Dead envs emit cost=0, done=0 and hold.  done_step (B,) int32 must be          \
+       initialised to -1 before t=0.  u_out may be NULL. */                                           \
+    int hjbx_vhjb_step_##SFX(const hjbx_system* sys, const hjbx_task* task, int integrator, int t,    \
+                             int T_max, const T* x, const T* gradV, T* x_next, T* u_out, T* cost_t,   \
+                             T* done_t, int32_t* done_step, int64_t B, void* stream);                 \
+    /* Controller.get_control_efforts for the closed-form controllers, u (B,m). */      \
+    int hjbx_controller_##SFX(const hjbx_system* sys, const hjbx_controller* ctrl, const T* x, T* u,  \
+                              int64_t B, void* stream);                                               \
+    /* Whole closed loop in one kernel: for t in 0..T-1: u=ctrl(x); log; x=simulate(x,u)              \
+       (scripts/test_vhjb_policy.py:143-151, cartpole_energy_shaping.py:123-125).  With              \
+       HJBX_ROLLOUT_TERMINATE it follows rollout_trajectory (vhjb.py:171-193) with `task`:            \
+       per-step cost l*dt, terminal e'Pe, done_step.  Outputs (any may be NULL):                      \
+       traj (T+1,B,n) time-major states, u_log (T,B,m), cost (T+1,B), done_step (B,) int32,           \
+       total_cost (B,) sum of the emitted costs (get_trajectory_cost, vhjb.py:195-199).               \
+       task may be NULL when neither cost nor TERMINATE is requested. */                              \
+    int hjbx_rollout_feedback_##SFX(const hjbx_system* sys, const hjbx_task* task,                    \
+                                    const hjbx_controller* ctrl, int integrator, uint32_t flags,      \
+                                    int T_steps, const T* x0, T* traj, T* u_log, T* cost,             \
+                                    int32_t* done_step, T* total_cost, T* x_final, int64_t B,         \
+                                    void* stream);
+
+HJBX_DECLARE(float, f32)
+HJBX_DECLARE(double, f64)
+#undef HJBX_DECLARE
+
+/* ValueFunctionApproximator.__call__ + get_v_gradient (vhjb.py:17-60, 201-202) fused on the matrix
+ * cores: V (B,) and gradV (B,n) = dV/dx in one pass, weights staged in LDS.  f32 only (the JAX side
+ * of the reference is float32).  V or gradV may be NULL. */
+int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V,
+                        float* gradV, int64_t B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJBX_H */

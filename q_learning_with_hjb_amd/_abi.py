@@ -1,0 +1,259 @@
+"""ctypes binding of libhjbx.so (include/hjbx.h) -- the only way host code reaches the HIP kernels.
+
+There is no CPU implementation behind this module: if the shared library is missing, or there is
+no MI355X to run on, calls raise.  (The CPU oracle lives in /oracle and is test infrastructure.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+HJBX_MAX_N = 10
+HJBX_MAX_M = 3
+
+# enums of include/hjbx.h
+SYS_LINEAR, SYS_CARTPOLE, SYS_ACROBOT, SYS_QUAD2D, SYS_NEARHOVER = range(5)
+EULER, RK4 = 0, 1
+RESIDUAL_NORMALISED, RESIDUAL_RAW = 0, 1
+CTRL_LINEAR_FEEDBACK, CTRL_CARTPOLE_ENERGY, CTRL_ACROBOT_ENERGY = 0, 1, 2
+ROLLOUT_TERMINATE = 1
+OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
+_SOURCES = ("hjbx_kernels.hip", "hjbx_mlp.hip")
+_HEADERS = ("hjbx_systems.hpp", os.path.join("..", "..", "include", "hjbx.h"))
+
+
+class HjbxTask(C.Structure):
+    """struct hjbx_task"""
+    _fields_ = [
+        ("Q", C.c_double * (HJBX_MAX_N * HJBX_MAX_N)),
+        ("R", C.c_double * (HJBX_MAX_M * HJBX_MAX_M)),
+        ("Rinv", C.c_double * (HJBX_MAX_M * HJBX_MAX_M)),
+        ("P", C.c_double * (HJBX_MAX_N * HJBX_MAX_N)),
+        ("xf", C.c_double * HJBX_MAX_N),
+        ("uf", C.c_double * HJBX_MAX_M),
+        ("obs_min", C.c_double * HJBX_MAX_N),
+        ("obs_max", C.c_double * HJBX_MAX_N),
+        ("eps", C.c_double),
+    ]
+
+
+class HjbxController(C.Structure):
+    """struct hjbx_controller"""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("wrap_error", C.c_int32),
+        ("K", C.c_double * (HJBX_MAX_M * HJBX_MAX_N)),
+        ("xf", C.c_double * HJBX_MAX_N),
+        ("uf", C.c_double * HJBX_MAX_M),
+        ("P", C.c_double * (HJBX_MAX_N * HJBX_MAX_N)),
+        ("Kes", C.c_double * 3),
+        ("eps_energy", C.c_double),
+        ("eps_state", C.c_double),
+        ("eps_region", C.c_double),
+    ]
+
+
+class HjbxMlp(C.Structure):
+    """struct hjbx_mlp"""
+    _fields_ = [
+        ("W1", C.c_void_p),
+        ("W2", C.c_void_p),
+        ("W3", C.c_void_p),
+        ("h1", C.c_int32),
+        ("h2", C.c_int32),
+        ("h3", C.c_int32),
+        ("_pad", C.c_int32),
+        ("mean", C.c_double * HJBX_MAX_N),
+        ("std", C.c_double * HJBX_MAX_N),
+        ("xf", C.c_double * HJBX_MAX_N),
+        ("eps_scalar", C.c_double),
+    ]
+
+
+def _fill(dst, src):
+    a = np.asarray(src, dtype=np.float64).ravel()
+    if a.size > len(dst):
+        raise ValueError(f"descriptor field takes at most {len(dst)} values, got {a.size}")
+    for i, v in enumerate(a):
+        dst[i] = float(v)
+
+
+def make_task(n, m, Q, R, P, xf, uf, obs_min, obs_max, eps, Rinv=None) -> HjbxTask:
+    """Pack the task part of VHJBControllerConfig (+P) into struct hjbx_task."""
+    Q = np.asarray(Q, np.float64).reshape(n, n)
+    R = np.asarray(R, np.float64).reshape(m, m)
+    t = HjbxTask()
+    _fill(t.Q, Q)
+    _fill(t.R, R)
+    _fill(t.Rinv, np.linalg.inv(R) if Rinv is None else np.asarray(Rinv, np.float64).reshape(m, m))
+    _fill(t.P, np.zeros((n, n)) if P is None else np.asarray(P, np.float64).reshape(n, n))
+    _fill(t.xf, np.asarray(xf, np.float64).reshape(n))
+    _fill(t.uf, np.asarray(uf, np.float64).reshape(m))
+    _fill(t.obs_min, np.full(n, -np.inf) if obs_min is None else np.asarray(obs_min, np.float64).reshape(n))
+    _fill(t.obs_max, np.full(n, np.inf) if obs_max is None else np.asarray(obs_max, np.float64).reshape(n))
+    t.eps = float(eps)
+    return t
+
+
+def make_controller(kind, n, m, K, xf=None, uf=None, wrap_error=True, P=None, Kes=None, eps_energy=0.0,
+                    eps_state=0.0, eps_region=0.0) -> HjbxController:
+    c = HjbxController()
+    c.kind = int(kind)
+    c.wrap_error = 1 if wrap_error else 0
+    _fill(c.K, np.asarray(K, np.float64).reshape(m, n))
+    _fill(c.xf, np.zeros(n) if xf is None else np.asarray(xf, np.float64).reshape(n))
+    _fill(c.uf, np.zeros(m) if uf is None else np.asarray(uf, np.float64).reshape(m))
+    if P is not None:
+        _fill(c.P, np.asarray(P, np.float64).reshape(n, n))
+    if Kes is not None:
+        _fill(c.Kes, np.asarray(Kes, np.float64).reshape(3))
+    c.eps_energy = float(eps_energy)
+    c.eps_state = float(eps_state)
+    c.eps_region = float(eps_region)
+    return c
+
+
+# ------------------------------------------------------------------------------------------------
+# build + load
+# ------------------------------------------------------------------------------------------------
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libhjbx.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+    deps = srcs + [os.path.normpath(os.path.join(_CSRC, h)) for h in _HEADERS]
+    if not force and os.path.exists(_LIB_PATH):
+        if all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+            return _LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return _LIB_PATH
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_I64, _I32, _U32, _VP, _DBL = C.c_int64, C.c_int, C.c_uint32, C.c_void_p, C.c_double
+
+
+def _typed_signatures():
+    P = _VP
+    return {
+        "affine": [P, P, P, P, _I64, P],
+        "wrap": [P, P, P, _I64, P],
+        "dynamics_step": [P, P, P, P, _I64, P],
+        "simulate": [P, _I32, P, P, P, _I64, P],
+        "initial_state": [P, P, P, P, P, _I64, P],
+        "running_cost": [P, P, P, P, P, _I64, P],
+        "termination_cost": [P, P, P, P, _I64, P],
+        "control_from_grad": [P, P, P, P, P, _I64, P],
+        "hjb_residual": [P, P, _I32, P, P, P, P, P, P, P, _I64, P],
+        "termination_residual": [_DBL, P, P, P, P, P, P, P, _I64, P],
+        "vhjb_step": [P, P, _I32, _I32, _I32, P, P, P, P, P, P, P, _I64, P],
+        "controller": [P, P, P, P, _I64, P],
+        "rollout_feedback": [P, P, P, _I32, _U32, _I32, P, P, P, P, P, P, P, _I64, P],
+    }
+
+
+EXPORTED_SYMBOLS = (
+    ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
+     "hjbx_reduce_workspace_bytes", "hjbx_value_grad_f32"]
+    + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
+)
+
+
+def lib() -> C.CDLL:
+    """Load libhjbx.so (raises RuntimeError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"hjbx: {_LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the hot path)")
+        L = C.CDLL(_LIB_PATH)
+        L.hjbx_version.restype = C.c_int
+        L.hjbx_last_error.restype = C.c_size_t
+        L.hjbx_last_error.argtypes = [C.c_char_p, C.c_size_t]
+        L.hjbx_device_count.restype = C.c_int
+        L.hjbx_reduce_workspace_bytes.restype = C.c_size_t
+        L.hjbx_system_create.restype = C.c_int
+        L.hjbx_system_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]
+        L.hjbx_system_destroy.restype = None
+        L.hjbx_system_destroy.argtypes = [_VP]
+        L.hjbx_dims.restype = C.c_int
+        L.hjbx_dims.argtypes = [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hjbx_value_grad_f32.restype = C.c_int
+        L.hjbx_value_grad_f32.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _VP]
+        for name, sig in _typed_signatures().items():
+            for sfx in ("f32", "f64"):
+                fn = getattr(L, f"hjbx_{name}_{sfx}")
+                fn.restype = C.c_int
+                fn.argtypes = sig
+        _lib = L
+        return L
+
+
+class HjbxError(RuntimeError):
+    pass
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().hjbx_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int):
+    """Turn an hjbx_status into the exception the Python surface promises (Errors)."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == EINVAL:
+        raise ValueError(f"hjbx: {msg}")
+    if rc == EUNSUPPORTED:
+        raise NotImplementedError(f"hjbx: {msg}")
+    raise HjbxError(f"hjbx (status {rc}): {msg}")
+
+
+class SystemHandle:
+    """Owns an hjbx_system*; immutable after creation."""
+
+    def __init__(self, kind, n, m, dt, umin, umax, params):
+        self.kind, self.n, self.m, self.dt = int(kind), int(n), int(m), float(dt)
+        self.umin = np.ascontiguousarray(umin, np.float64).reshape(m)
+        self.umax = np.ascontiguousarray(umax, np.float64).reshape(m)
+        self.params = np.ascontiguousarray(params, np.float64).ravel()
+        h = _VP()
+        check(lib().hjbx_system_create(self.kind, self.n, self.m, self.dt, self.umin.ctypes.data, self.umax.ctypes.data,
+                                       self.params.ctypes.data, int(self.params.size), C.byref(h)))
+        self._h = h
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _lib is not None:
+            try:
+                _lib.hjbx_system_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+def ref(struct):
+    """pointer to a host descriptor struct (or None)"""
+    return None if struct is None else C.cast(C.pointer(struct), _VP)

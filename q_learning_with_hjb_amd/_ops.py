@@ -1,0 +1,216 @@
+"""Typed, tensor-level wrappers over the C ABI: torch CUDA tensors in, torch CUDA tensors out.
+
+PyTorch is plumbing here (device memory + the current HIP stream); every computation below is one
+of the hand-written gfx950 kernels in csrc/.  Inputs must be float32/float64 CUDA tensors; the
+public `Dynamics` / `Controller` classes do the numpy <-> device marshalling around these.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import check, lib, ref
+
+
+def require_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("hjbx: no HIP device visible -- the batched rollout / HJB path only runs on an MI355X "
+                           "(there is deliberately no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _sfx(t: torch.Tensor) -> str:
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"hjbx kernels take float32 or float64 tensors, got {t.dtype}")
+
+
+def _chk(t: torch.Tensor, name: str, shape, dtype=None):
+    if not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA (HIP) tensor")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} has dtype {t.dtype}, expected {dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+_ws = {}
+
+
+def _workspace(device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    w = _ws.get(key)
+    if w is None:
+        w = torch.empty(lib().hjbx_reduce_workspace_bytes() // 8, dtype=torch.float64, device=device)
+        _ws[key] = w
+    return w
+
+
+def _fn(name, t):
+    return getattr(lib(), f"hjbx_{name}_{_sfx(t)}")
+
+
+def affine(sys, x):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    f1 = torch.empty_like(x)
+    f2 = torch.empty((B, sys.n, sys.m), dtype=x.dtype, device=x.device)
+    check(_fn("affine", x)(sys.ptr, _p(x), _p(f1), _p(f2), B, _stream()))
+    return f1, f2
+
+
+def wrap(sys, x, out=None):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    out = torch.empty_like(x) if out is None else out
+    _chk(out, "out", (B, sys.n), x.dtype)
+    check(_fn("wrap", x)(sys.ptr, _p(x), _p(out), B, _stream()))
+    return out
+
+
+def dynamics_step(sys, x, u):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    _chk(u, "u", (B, sys.m), x.dtype)
+    xd = torch.empty_like(x)
+    check(_fn("dynamics_step", x)(sys.ptr, _p(x), _p(u), _p(xd), B, _stream()))
+    return xd
+
+
+def simulate(sys, x, u, integrator=_abi.EULER, out=None):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    _chk(u, "u", (B, sys.m), x.dtype)
+    out = torch.empty_like(x) if out is None else out
+    _chk(out, "out", (B, sys.n), x.dtype)
+    check(_fn("simulate", x)(sys.ptr, int(integrator), _p(x), _p(u), _p(out), B, _stream()))
+    return out
+
+
+def initial_state(sys, x0_mean, x0_std, u01):
+    import numpy as np
+    B = u01.shape[0]
+    _chk(u01, "u01", (B, sys.n))
+    mean = np.ascontiguousarray(x0_mean, np.float64).reshape(sys.n)
+    std = np.ascontiguousarray(x0_std, np.float64).reshape(sys.n)
+    x0 = torch.empty_like(u01)
+    check(_fn("initial_state", u01)(sys.ptr, mean.ctypes.data, std.ctypes.data, _p(u01), _p(x0), B, _stream()))
+    return x0
+
+
+def running_cost(sys, task, x, u):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    _chk(u, "u", (B, sys.m), x.dtype)
+    c = torch.empty((B,), dtype=x.dtype, device=x.device)
+    check(_fn("running_cost", x)(sys.ptr, ref(task), _p(x), _p(u), _p(c), B, _stream()))
+    return c
+
+
+def termination_cost(sys, task, x):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    c = torch.empty((B,), dtype=x.dtype, device=x.device)
+    check(_fn("termination_cost", x)(sys.ptr, ref(task), _p(x), _p(c), B, _stream()))
+    return c
+
+
+def control_from_grad(sys, task, x, grad_v):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    _chk(grad_v, "grad_v", (B, sys.n), x.dtype)
+    u = torch.empty((B, sys.m), dtype=x.dtype, device=x.device)
+    check(_fn("control_from_grad", x)(sys.ptr, ref(task), _p(x), _p(grad_v), _p(u), B, _stream()))
+    return u
+
+
+def hjb_residual(sys, task, x, grad_v, done, mode=_abi.RESIDUAL_NORMALISED, want_loss=True, want_grad=True, want_sums=True):
+    """-> (loss_i (B,) | None, dloss_dgrad (B,n) | None, sums (3,) | None)"""
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    _chk(grad_v, "grad_v", (B, sys.n), x.dtype)
+    _chk(done, "done", (B,), x.dtype)
+    li = torch.empty((B,), dtype=x.dtype, device=x.device) if want_loss else None
+    dg = torch.empty_like(x) if want_grad else None
+    sums = torch.empty((3,), dtype=x.dtype, device=x.device) if want_sums else None
+    ws = _workspace(x.device) if want_sums else None
+    check(_fn("hjb_residual", x)(sys.ptr, ref(task), int(mode), _p(x), _p(grad_v), _p(done), _p(li), _p(dg), _p(sums),
+                                 _p(ws), B, _stream()))
+    return li, dg, sums
+
+
+def termination_residual(eps, V, cost, done, want_loss=True, want_grad=True, want_sums=True):
+    B = V.shape[0]
+    _chk(V, "V", (B,))
+    _chk(cost, "cost", (B,), V.dtype)
+    _chk(done, "done", (B,), V.dtype)
+    li = torch.empty_like(V) if want_loss else None
+    dv = torch.empty_like(V) if want_grad else None
+    sums = torch.empty((3,), dtype=V.dtype, device=V.device) if want_sums else None
+    ws = _workspace(V.device) if want_sums else None
+    check(_fn("termination_residual", V)(float(eps), _p(V), _p(cost), _p(done), _p(li), _p(dv), _p(sums), _p(ws), B, _stream()))
+    return li, dv, sums
+
+
+def vhjb_step(sys, task, t, T_max, x, grad_v, x_next, cost_t, done_t, done_step, u_out=None, integrator=_abi.EULER):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    _chk(grad_v, "grad_v", (B, sys.n), x.dtype)
+    _chk(x_next, "x_next", (B, sys.n), x.dtype)
+    _chk(cost_t, "cost_t", (B,), x.dtype)
+    _chk(done_t, "done_t", (B,), x.dtype)
+    _chk(done_step, "done_step", (B,), torch.int32)
+    if u_out is not None:
+        _chk(u_out, "u_out", (B, sys.m), x.dtype)
+    check(_fn("vhjb_step", x)(sys.ptr, ref(task), int(integrator), int(t), int(T_max), _p(x), _p(grad_v), _p(x_next), _p(u_out),
+                              _p(cost_t), _p(done_t), _p(done_step), B, _stream()))
+
+
+def controller(sys, ctrl, x):
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n))
+    u = torch.empty((B, sys.m), dtype=x.dtype, device=x.device)
+    check(_fn("controller", x)(sys.ptr, ref(ctrl), _p(x), _p(u), B, _stream()))
+    return u
+
+
+def rollout_feedback(sys, ctrl, x0, T_steps, task=None, integrator=_abi.EULER, terminate=False, log_traj=True, log_u=False,
+                     log_cost=False):
+    """Whole closed loop in one kernel launch.  Returns a dict of device tensors (time-major)."""
+    B = x0.shape[0]
+    _chk(x0, "x0", (B, sys.n))
+    dt, dev = x0.dtype, x0.device
+    traj = torch.empty((T_steps + 1, B, sys.n), dtype=dt, device=dev) if log_traj else None
+    ulog = torch.empty((T_steps, B, sys.m), dtype=dt, device=dev) if log_u else None
+    cost = torch.empty((T_steps + 1, B), dtype=dt, device=dev) if (log_cost and task is not None) else None
+    total = torch.empty((B,), dtype=dt, device=dev) if task is not None else None
+    done_step = torch.empty((B,), dtype=torch.int32, device=dev)
+    x_final = torch.empty_like(x0)
+    flags = _abi.ROLLOUT_TERMINATE if terminate else 0
+    check(_fn("rollout_feedback", x0)(sys.ptr, ref(task), ref(ctrl), int(integrator), flags, int(T_steps), _p(x0), _p(traj),
+                                      _p(ulog), _p(cost), _p(done_step), _p(total), _p(x_final), B, _stream()))
+    return dict(traj=traj, u=ulog, cost=cost, done_step=done_step, total_cost=total, x_final=x_final)
+
+
+def value_grad(sys, mlp_desc, x, want_v=True, want_grad=True):
+    """Fused MFMA value network forward + input gradient (f32 only)."""
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n), torch.float32)
+    V = torch.empty((B,), dtype=x.dtype, device=x.device) if want_v else None
+    g = torch.empty_like(x) if want_grad else None
+    check(lib().hjbx_value_grad_f32(sys.ptr, ref(mlp_desc), _p(x), _p(V), _p(g), B, _stream()))
+    return V, g

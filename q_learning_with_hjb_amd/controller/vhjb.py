@@ -1,0 +1,495 @@
+"""VHJBController -- value-function learning with the HJB residual (reference controller/vhjb.py).
+
+Split of labour (BASELINE.json north_star):
+  * HIP kernels (libhjbx.so): control law, running/terminal cost, the closed-loop rollout step, the HJB
+    and termination residuals with their analytic gradients, angle wrap, initial states, and -- for
+    float32 -- the value network forward + input gradient fused on the matrix cores.
+  * PyTorch-ROCm: the value-network parameters, their gradients (autograd through a few matmuls) and
+    Adam; torch.distributed (RCCL) for ONE flat all-reduce per optimiser step.
+
+Rollouts are batched: B independent copies of the reference's batch-1 loop (vhjb.py:171-193) advance
+in lock-step, state resident in HBM, time-major logs `(T+1, B, ...)`.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _abi, _ops
+from ..dynamics.dynamics_basic import Dynamics, _from_device, _to_device
+from ..utils.utils import linearize, solve_continuous_are
+from .controller_basic import Controller
+
+
+# ------------------------------------------------------------------------------------------------
+# value network
+# ------------------------------------------------------------------------------------------------
+def lecun_normal_(w: torch.Tensor, generator=None):
+    """Flax's default Dense init: truncated normal (+-2 sigma), variance 1/fan_in.
+    `w` has the Flax kernel layout (in, out)."""
+    fan_in = w.shape[0]
+    std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+    with torch.no_grad():
+        torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=generator)
+        w.mul_(std)
+    return w
+
+
+class ValueFunctionApproximator(torch.nn.Module):
+    """V(x) = ||MLP((e - mean)/std)||^2 + eps_s ||e||^2,  e = wrap(x - xf); bias-free Dense layers
+    with ReLU between them so that V(xf) = 0 (reference vhjb.py:17-60).  Kernels are stored
+    (in, out) and applied as `x @ W`, like Flax."""
+
+    def __init__(self, dynamics: Dynamics, features: Sequence[int], mean, std, xf, epsilon_scalar: float,
+                 using_batch_norm: bool = False, dtype=torch.float32, device=None, generator=None):
+        super().__init__()
+        if using_batch_norm:
+            raise NotImplementedError("BatchNorm is disabled in every reference config and is not implemented")
+        if len(features) != 3:
+            raise NotImplementedError("the fused kernel and this module take exactly three Dense layers")
+        self.dynamics = dynamics
+        self.features = tuple(int(f) for f in features)
+        n = dynamics.state_dim
+        dims = (n,) + self.features
+        self.weights = torch.nn.ParameterList()
+        for i in range(3):
+            w = torch.empty((dims[i], dims[i + 1]), dtype=dtype, device=device)
+            self.weights.append(torch.nn.Parameter(lecun_normal_(w, generator)))
+        self.register_buffer("mean", torch.as_tensor(np.asarray(mean, np.float64), dtype=dtype, device=device))
+        self.register_buffer("std", torch.as_tensor(np.asarray(std, np.float64), dtype=dtype, device=device))
+        self.register_buffer("xf", torch.as_tensor(np.asarray(xf, np.float64), dtype=dtype, device=device))
+        self.epsilon_scalar = float(epsilon_scalar)
+        self._np = dict(mean=np.asarray(mean, np.float64), std=np.asarray(std, np.float64), xf=np.asarray(xf, np.float64))
+
+    # error coordinates are data: nothing is differentiated through the wrap
+    def error_coords(self, x: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            return _ops.wrap(self.dynamics.system, (x - self.xf).contiguous())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        V, _ = self.value_and_grad(x, want_grad=False)
+        return V
+
+    def value_and_grad(self, x: torch.Tensor, want_grad: bool = True):
+        """V (B,) and dV/dx (B, n) as differentiable functions of the weights.
+
+        The input gradient is written out as reverse mode by hand (three transposed matmuls with the
+        ReLU masks), which keeps d(grad)/d(weights) a plain first-order autograd graph -- the
+        "double back-prop" of vhjb.py:282 without create_graph."""
+        W1, W2, W3 = self.weights
+        e = self.error_coords(x)
+        z = (e - self.mean) / self.std
+        a1 = z @ W1
+        h1 = torch.relu(a1)
+        a2 = h1 @ W2
+        h2 = torch.relu(a2)
+        y = h2 @ W3
+        V = (y * y).sum(-1) + self.epsilon_scalar * (e * e).sum(-1)
+        if not want_grad:
+            return V, None
+        d2 = ((2.0 * y) @ W3.t()) * (a2 > 0)
+        d1 = (d2 @ W2.t()) * (a1 > 0)
+        g = (d1 @ W1.t()) / self.std + (2.0 * self.epsilon_scalar) * e
+        return V, g
+
+    def descriptor(self) -> _abi.HjbxMlp:
+        d = _abi.HjbxMlp()
+        W1, W2, W3 = self.weights
+        d.W1, d.W2, d.W3 = W1.data_ptr(), W2.data_ptr(), W3.data_ptr()
+        d.h1, d.h2, d.h3 = self.features
+        _abi._fill(d.mean, self._np["mean"])
+        _abi._fill(d.std, self._np["std"])
+        _abi._fill(d.xf, self._np["xf"])
+        d.eps_scalar = self.epsilon_scalar
+        return d
+
+    @torch.no_grad()
+    def fused_value_grad(self, x: torch.Tensor, want_v=True, want_grad=True):
+        """Inference-only V and dV/dx from the fused MFMA kernel (float32)."""
+        for w in self.weights:
+            assert w.is_contiguous() and w.dtype == torch.float32
+        return _ops.value_grad(self.dynamics.system, self.descriptor(), x, want_v, want_grad)
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd bridges to the residual kernels (forward value + analytic first derivative)
+# ------------------------------------------------------------------------------------------------
+class _HJBResidualSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grad_v, x, done, sys, task, mode):
+        _, dg, sums = _ops.hjb_residual(sys, task, x, grad_v.detach().contiguous(), done, mode, want_loss=False)
+        ctx.save_for_backward(dg)
+        ctx.mark_non_differentiable(sums)
+        return sums[0].clone(), sums
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out, _grad_sums):
+        (dg,) = ctx.saved_tensors
+        return grad_out * dg, None, None, None, None, None
+
+
+class _TerminationResidualSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, V, cost, done, eps):
+        _, dv, sums = _ops.termination_residual(eps, V.detach().contiguous(), cost, done, want_loss=False)
+        ctx.save_for_backward(dv)
+        ctx.mark_non_differentiable(sums)
+        return sums[0].clone(), sums
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out, _grad_sums):
+        (dv,) = ctx.saved_tensors
+        return grad_out * dv, None, None, None
+
+
+def sgdr_schedule(step: int, init_value: float, peak_value: float, end_value: float, warmup_steps: int, decay_steps: int,
+                  num_cycles: int) -> float:
+    """optax.sgdr_schedule of `num_cycles` identical warm-up + cosine-decay cycles (vhjb.py:122-126;
+    semantics assumed in SURVEY A.4): linear init->peak over `warmup_steps`, cosine peak->end over
+    the remaining `decay_steps - warmup_steps`; after the last cycle it holds `end_value`."""
+    c = min(int(step) // decay_steps, num_cycles - 1)
+    local = int(step) - c * decay_steps
+    if local < warmup_steps:
+        return init_value + (peak_value - init_value) * local / warmup_steps
+    span = decay_steps - warmup_steps
+    k = min(local - warmup_steps, span)
+    cos = 0.5 * (1.0 + math.cos(math.pi * k / span))
+    alpha = end_value / peak_value if peak_value != 0 else 0.0
+    return peak_value * ((1 - alpha) * cos + alpha)
+
+
+class ReplayBuffer:
+    """Device-resident FIFO of (x, cost, done) records (reference StatesDataset: deque(maxlen),
+    vhjb.py:62-73) with shuffle-without-replacement, drop-last minibatches (the DataLoader of :154)."""
+
+    def __init__(self, n: int, capacity: int, dtype, device):
+        self.capacity = int(capacity)
+        self.x = torch.empty((self.capacity, n), dtype=dtype, device=device)
+        self.cost = torch.empty((self.capacity,), dtype=dtype, device=device)
+        self.done = torch.empty((self.capacity,), dtype=dtype, device=device)
+        self.size = 0
+        self.head = 0  # next write slot
+
+    def __len__(self):
+        return self.size
+
+    def extend(self, x: torch.Tensor, cost: torch.Tensor, done: torch.Tensor):
+        k = x.shape[0]
+        if k == 0:
+            return
+        if k >= self.capacity:
+            x, cost, done = x[-self.capacity:], cost[-self.capacity:], done[-self.capacity:]
+            k = self.capacity
+        idx = (self.head + torch.arange(k, device=self.x.device)) % self.capacity
+        self.x[idx] = x
+        self.cost[idx] = cost
+        self.done[idx] = done
+        self.head = (self.head + k) % self.capacity
+        self.size = min(self.capacity, self.size + k)
+
+    def num_batches(self, batch_size: int) -> int:
+        return self.size // batch_size
+
+    def batches(self, batch_size: int, generator=None, limit: Optional[int] = None):
+        nb = self.num_batches(batch_size)
+        if limit is not None:
+            nb = min(nb, limit)
+        if nb == 0:
+            return
+        perm = torch.randperm(self.size, device=self.x.device, generator=generator)
+        for b in range(nb):
+            idx = perm[b * batch_size:(b + 1) * batch_size]
+            yield self.x[idx], self.cost[idx], self.done[idx]
+
+
+class VHJBController(Controller):
+
+    def __init__(self, dynamics: Dynamics, config, device=None, dtype=torch.float32, process_group=None,
+                 residual_mode=_abi.RESIDUAL_NORMALISED, fused_value_grad: Optional[bool] = None) -> None:
+        super().__init__()
+        self.device = torch.device(device) if device is not None else _ops.require_device()
+        self.dtype = dtype
+        self.process_group = process_group
+        self.world_size = torch.distributed.get_world_size(process_group) if self._distributed() else 1
+        self.rank = torch.distributed.get_rank(process_group) if self._distributed() else 0
+
+        # seeds (vhjb.py:80-83); ranks > 0 offset theirs so the shards roll out different environments
+        torch.manual_seed(config.seed + self.rank)
+        np.random.seed(config.seed + self.rank)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(config.seed + self.rank)
+        self._init_gen = torch.Generator(device=self.device)
+        self._init_gen.manual_seed(config.seed)  # identical initial weights on every rank
+
+        self.epsilon = float(config.epsilon)
+        self.dynamics = dynamics
+        self.state_dim, self.control_dim = dynamics.get_dimension()
+        self.umin, self.umax = dynamics.get_control_limit()
+        assert self.umin.shape[0] == self.control_dim
+        assert self.umax.shape[0] == self.control_dim
+        self.Q, self.R = config.Q, config.R
+        self.R_inv = np.linalg.inv(np.asarray(self.R, np.float64))
+        self.xf, self.uf = config.xf, config.uf
+        self.obs_min, self.obs_max = config.obs_min, config.obs_max
+        self.residual_mode = residual_mode
+
+        self.system_additional_init()
+        self._task = _abi.make_task(self.state_dim, self.control_dim, self.Q, self.R, self.P, self.xf, self.uf, self.obs_min,
+                                    self.obs_max, self.epsilon, Rinv=self.R_inv)
+
+        self.value_function_approximator = ValueFunctionApproximator(
+            dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
+            config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen)
+        self.fused_value_grad = (dtype == torch.float32) if fused_value_grad is None else bool(fused_value_grad)
+        self.train_mode = False
+        self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=config.lr, betas=(0.9, 0.999), eps=1e-8)
+        self._sched = dict(init_value=config.regularization_init_value, peak_value=config.regularization_peak_value,
+                           end_value=config.regularization_end_value, warmup_steps=config.regularization_warmup_steps_per_cycle,
+                           decay_steps=config.regularization_total_steps_per_cycle, num_cycles=config.regularization_num_of_cycles)
+        self.update_counter = 0
+        self.regularization = self.regularization_scheduler(self.update_counter)
+        self.epochs = config.epochs
+        self.batch_size = config.batch_size
+
+        self.maximum_timestep = config.maximum_step
+        self.num_of_trajectories_per_epoch = config.num_of_trajectories_per_epoch
+
+        # seed data set: interior points (cost 0, done 0) and boundary points (cost=min(e'Pe, clip), done 1), vhjb.py:136-150
+        n = self.state_dim
+
+        def draw(count, mean, std):
+            pts = np.stack([np.random.uniform(low=-1, high=1, size=n) * std + mean for _ in range(count)]) if count else np.zeros((0, n))
+            return self._dev(pts)
+
+        interior = draw(config.num_of_interior_data, config.interior_states_mean, config.interior_states_std)
+        boundary = draw(config.num_of_boundary_data, config.boundary_states_mean, config.boundary_states_std)
+        self.replay_buffer = ReplayBuffer(n, config.maximum_buffer_size, dtype, self.device)
+        if interior.shape[0]:
+            interior = _ops.wrap(dynamics.system, interior)
+            z = torch.zeros(interior.shape[0], dtype=dtype, device=self.device)
+            self.replay_buffer.extend(interior, z, z)
+        if boundary.shape[0]:
+            boundary = _ops.wrap(dynamics.system, boundary)
+            bc = torch.clamp(_ops.termination_cost(dynamics.system, self._task, boundary), max=float(config.boundary_cost_clip))
+            self.replay_buffer.extend(boundary, bc, torch.ones_like(bc))
+
+    # ---------------------------------------------------------------------------------------------
+    def _distributed(self) -> bool:
+        return torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            (self.process_group is not None or torch.distributed.get_world_size() > 1)
+
+    def _dev(self, a) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=self.dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, np.float64), dtype=self.dtype, device=self.device).contiguous()
+
+    def regularization_scheduler(self, step: int) -> float:
+        return sgdr_schedule(step, **self._sched)
+
+    def system_additional_init(self) -> None:
+        """Linearise about (xf, uf), assume f(xf, uf) = 0, solve the CARE for the terminal cost P (vhjb.py:156-160)."""
+        Alin, Blin = linearize(self.dynamics, self.xf, self.uf)
+        self.Alin, self.Blin = Alin, Blin
+        self.P = solve_continuous_are(Alin, Blin, self.Q, self.R)
+
+    # -- costs (vhjb.py:162-169), batched ---------------------------------------------------------------
+    def running_cost(self, x, u):
+        t, one, kind = _to_device(x)
+        ut = self.dynamics._control_like(u, t)
+        return _from_device(_ops.running_cost(self.dynamics.system, self._task, t, ut), one, kind)
+
+    def termination_cost(self, x):
+        t, one, kind = _to_device(x)
+        return _from_device(_ops.termination_cost(self.dynamics.system, self._task, t), one, kind)
+
+    # -- control law (vhjb.py:201-225) -----------------------------------------------------------------
+    @torch.no_grad()
+    def get_v_gradient(self, x: torch.Tensor) -> torch.Tensor:
+        """dV/dx for a (B, n) device batch (inference)."""
+        if self.fused_value_grad and x.dtype == torch.float32:
+            return self.value_function_approximator.fused_value_grad(x, want_v=False)[1]
+        return self.value_function_approximator.value_and_grad(x)[1]
+
+    @torch.no_grad()
+    def get_control_efforts_with_additional_term(self, x) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (u, v_gradient) on the device for x (B, n) / (n,)"""
+        t, one, kind = _to_device(x, like_dtype=self.dtype)
+        g = self.get_v_gradient(t)
+        u = _ops.control_from_grad(self.dynamics.system, self._task, t, g)
+        return _from_device(u, one, kind), _from_device(g, one, kind)
+
+    def get_control_efforts(self, x):
+        return self.get_control_efforts_with_additional_term(x)[0]
+
+    # -- rollouts --------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def rollout_batch(self, x0: torch.Tensor, max_steps: Optional[int] = None, log_u: bool = False):
+        """B closed loops in lock-step (the batch twin of rollout_trajectory, vhjb.py:171-193).
+
+        x0 (B, n) on the device.  Returns time-major device tensors: traj (T+1, B, n), cost (T+1, B),
+        done (T+1, B), done_step (B,) int32 [index of each env's terminal tuple], u (T, B, m) | None.
+        Tuple t of env b is valid iff t <= done_step[b]."""
+        T = self.maximum_timestep if max_steps is None else int(max_steps)
+        x0 = x0.to(dtype=self.dtype, device=self.device).contiguous()
+        B, n = x0.shape
+        sysh, task, integ = self.dynamics.system, self._task, self.dynamics.integrator
+        traj = torch.empty((T + 2, B, n), dtype=self.dtype, device=self.device)  # slot T+1 is scratch for the last call
+        cost = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)
+        done = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)
+        ulog = torch.empty((T, B, self.control_dim), dtype=self.dtype, device=self.device) if log_u else None
+        done_step = torch.full((B,), -1, dtype=torch.int32, device=self.device)
+        traj[0].copy_(x0)
+        g = None
+        for t in range(T + 1):
+            if t < T or g is None:
+                g = self.get_v_gradient(traj[t])
+            _ops.vhjb_step(sysh, task, t, T, traj[t], g, traj[t + 1], cost[t], done[t], done_step,
+                           u_out=(ulog[t] if (log_u and t < T) else None), integrator=integ)
+        return dict(traj=traj[:T + 1], cost=cost, done=done, done_step=done_step, u=ulog)
+
+    def rollout_trajectory(self) -> List[Tuple[np.ndarray, float, float]]:
+        """One trajectory as the reference returns it: a list of (x, cost, done) tuples."""
+        x0 = self._dev(self.dynamics.get_initial_state(batch_size=1))
+        out = self.rollout_batch(x0)
+        L = int(out["done_step"][0].item()) + 1
+        xs = out["traj"][:L, 0].cpu().numpy()
+        cs = out["cost"][:L, 0].cpu().numpy()
+        ds = out["done"][:L, 0].cpu().numpy()
+        return [(xs[i], float(cs[i]), float(ds[i])) for i in range(L)]
+
+    def get_trajectory_cost(self, trajectory):
+        total_cost = 0.0
+        for x, cost, done in trajectory:
+            total_cost += cost
+        return total_cost
+
+    # -- losses (vhjb.py:227-253) ----------------------------------------------------------------------
+    def _hjb_sums(self, xs, dones):
+        _, g = self.value_function_approximator.value_and_grad(xs)
+        return _HJBResidualSum.apply(g, xs, dones, self.dynamics.system, self._task, self.residual_mode)
+
+    def _termination_sums(self, xs, dones, costs):
+        V, _ = self.value_function_approximator.value_and_grad(xs, want_grad=False)
+        return _TerminationResidualSum.apply(V, costs, dones, self.epsilon)
+
+    def hjb_loss(self, xs, dones):
+        xs, dones = self._dev(xs), self._dev(dones)
+        s, sums = self._hjb_sums(xs, dones)
+        return s / (sums[1] + self.epsilon)
+
+    def termination_loss(self, xs, dones, costs):
+        xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
+        s, sums = self._termination_sums(xs, dones, costs)
+        return s / (sums[2] + self.epsilon)
+
+    def params_update(self, xs, dones, costs, regularization):
+        """One optimiser step (vhjb.py:255-288): grad(hjb) + regularization * grad(termination), Adam.
+
+        Data parallel: every rank contributes the gradient of its loss SUMS and its counts through
+        ONE flat all-reduce; the division by the global counts happens afterwards, so the result equals
+        the single-process update on the concatenated minibatch.  Returns (total, hjb, termination) losses."""
+        xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
+        params = list(self.value_function_approximator.parameters())
+        V, g = self.value_function_approximator.value_and_grad(xs)
+        h_sum, h_sums = _HJBResidualSum.apply(g, xs, dones, self.dynamics.system, self._task, self.residual_mode)
+        t_sum, _ = _TerminationResidualSum.apply(V, costs, dones, self.epsilon)
+        g_h = torch.autograd.grad(h_sum, params, retain_graph=True, allow_unused=True)
+        g_t = torch.autograd.grad(t_sum, params, allow_unused=True)
+        flat = pack_flat(g_h, g_t, params, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]))
+        if self._distributed():
+            torch.distributed.all_reduce(flat, group=self.process_group)
+        g_h, g_t, (hs, ts, n_int, n_done) = unpack_flat(flat, params)
+        hjb_loss = hs / (n_int + self.epsilon)
+        termination_loss = ts / (n_done + self.epsilon)
+        for p, a, b in zip(params, g_h, g_t):
+            p.grad = a / (n_int + self.epsilon) + regularization * (b / (n_done + self.epsilon))
+        self.optimizer.step()
+        return hjb_loss + regularization * termination_loss, hjb_loss, termination_loss
+
+    # -- training loop (vhjb.py:290-343) ---------------------------------------------------------------
+    def train(self):
+        average_trajectory_cost_list = []
+        std_trajectory_cost_list = []
+        average_trajectory_length_list = []
+        average_total_loss_list = []
+        average_hjb_loss_list = []
+        average_termination_loss_list = []
+
+        per_rank_batch = max(1, self.batch_size // self.world_size)
+        for epoch in range(self.epochs):
+            self.train_mode = False
+            ntraj = self.num_of_trajectories_per_epoch
+            if ntraj > 0:
+                x0 = self._dev(self.dynamics.get_initial_state(batch_size=ntraj))
+                out = self.rollout_batch(x0)
+                ds = out["done_step"].long()
+                valid = (torch.arange(self.maximum_timestep + 1, device=self.device)[:, None] <= ds[None, :])  # (T+1, B)
+                traj_costs = (out["cost"] * valid).sum(0).double().cpu().numpy()
+                trajectory_lengths = int((ds + 1).sum().item())
+                vm = valid.t().reshape(-1)  # trajectory-major, like extending the deque trajectory by trajectory
+                self.replay_buffer.extend(out["traj"].transpose(0, 1).reshape(-1, self.state_dim)[vm],
+                                          out["cost"].t().reshape(-1)[vm], out["done"].t().reshape(-1)[vm])
+            # fit the value function
+            total_losses = hjb_losses = termination_losses = 0.0
+            self.train_mode = True
+            nb = self.replay_buffer.num_batches(per_rank_batch)
+            if self._distributed():
+                nbt = torch.tensor([nb], device=self.device)
+                torch.distributed.all_reduce(nbt, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+                nb = int(nbt.item())
+            for xs, costs, dones in self.replay_buffer.batches(per_rank_batch, generator=self._gen, limit=nb):
+                total_loss, hjb_loss, termination_loss = self.params_update(xs, dones, costs, self.regularization)
+                total_losses = total_losses + total_loss
+                hjb_losses = hjb_losses + hjb_loss
+                termination_losses = termination_losses + termination_loss
+                self.update_counter += 1
+                self.regularization = self.regularization_scheduler(self.update_counter)
+
+            if ntraj > 0:
+                average_trajectory_cost_list.append(float(traj_costs.sum() / ntraj))
+                std_trajectory_cost_list.append(float(np.var(traj_costs) ** 0.5))
+                average_trajectory_length_list.append(trajectory_lengths / ntraj)
+            if nb != 0:
+                average_total_loss_list.append(float(total_losses / nb))
+                average_hjb_loss_list.append(float(hjb_losses / nb))
+                average_termination_loss_list.append(float(termination_losses / nb))
+            if (epoch + 1) % 10 == 0 and self.rank == 0:
+                if ntraj > 0:
+                    print(f"epoch:{epoch+1}, average trajectory cost:{average_trajectory_cost_list[-1]:.2f}, "
+                          f"average trajectory length:{average_trajectory_length_list[-1]:.2f}")
+                if nb != 0:
+                    print(f"epoch:{epoch+1}, total loss:{average_total_loss_list[-1]:.5f}, regulation: {self.regularization:.1e},"
+                          f"hjb loss:{average_hjb_loss_list[-1]:.5f}, termination loss:{average_termination_loss_list[-1]:.5f}")
+
+        return (average_trajectory_cost_list, std_trajectory_cost_list, average_trajectory_length_list,
+                average_total_loss_list, average_hjb_loss_list, average_termination_loss_list)
+
+
+# ------------------------------------------------------------------------------------------------
+# flat gradient buffer for the single all-reduce
+# ------------------------------------------------------------------------------------------------
+def pack_flat(g_h, g_t, params, scalars) -> torch.Tensor:
+    """[grad of sum(hjb) | grad of sum(termination) | scalars...] as one contiguous buffer."""
+    parts = []
+    for gs in (g_h, g_t):
+        for p, g in zip(params, gs):
+            parts.append((torch.zeros_like(p) if g is None else g).reshape(-1))
+    parts.append(torch.stack([s.reshape(()).to(parts[0].dtype) for s in scalars]))
+    return torch.cat(parts)
+
+
+def unpack_flat(flat: torch.Tensor, params):
+    out, off = [], 0
+    for _ in range(2):
+        gs = []
+        for p in params:
+            k = p.numel()
+            gs.append(flat[off:off + k].view_as(p))
+            off += k
+        out.append(gs)
+    return out[0], out[1], tuple(flat[off + i] for i in range(flat.numel() - off))

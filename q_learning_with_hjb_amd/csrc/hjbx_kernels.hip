@@ -1,0 +1,854 @@
+// hjbx_kernels.hip -- gfx950 kernels + C ABI (include/hjbx.h) for batched control-affine rollouts
+// and HJB residuals.  MI355X only: wave64, one lane per environment, state vectors in VGPRs,
+// system/task constants in SGPRs (kernarg), row-vector global accesses, wave-shuffle reductions.
+//
+// All of these kernels are HBM-bandwidth bound (a few dozen flops + one sincos per 36-128 bytes);
+// algorithmic byte counts per environment are tabulated in DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/hjbx.h"
+#include "hjbx_systems.hpp"
+
+using namespace hjbx;
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int hjbx_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HJBX_REQUIRE(cond, ...)                                  \
+    do {                                                         \
+        if (!(cond)) return hjbx_set_error(HJBX_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return HJBX_OK;
+}
+
+struct hjbx_system {
+    int kind, n, m;
+    double dt;
+    double umin[HJBX_MAX_M], umax[HJBX_MAX_M];
+    double p[HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M];
+    int n_params;
+};
+
+// ----------------------------------------------------------------------------------------------
+// row-vector global memory access: a (B, N) row-major row is moved with the widest naturally
+// aligned vector the row size allows (16 B for n=4 f32: one global_load_dwordx4 per lane).
+// ----------------------------------------------------------------------------------------------
+template <int BYTES> struct VecOf;
+template <> struct VecOf<16> { using type = uint4; };
+template <> struct VecOf<8> { using type = uint2; };
+template <> struct VecOf<4> { using type = uint32_t; };
+
+template <typename T, int N> struct RowIO {
+    static constexpr int BYTES = N * (int)sizeof(T);
+    static constexpr int W = (BYTES % 16 == 0) ? 16 : (BYTES % 8 == 0) ? 8 : 4;
+    static constexpr int CNT = BYTES / W;
+    using V = typename VecOf<W>::type;
+    static HJBX_DEV void load(const T* base, int64_t row, T* out) {
+        const V* p = reinterpret_cast<const V*>(base + row * N);
+        union { V v[CNT]; T t[N]; } u;
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) u.v[k] = p[k];
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = u.t[i];
+    }
+    static HJBX_DEV void store(T* base, int64_t row, const T* in) {
+        V* p = reinterpret_cast<V*>(base + row * N);
+        union { V v[CNT]; T t[N]; } u;
+#pragma unroll
+        for (int i = 0; i < N; ++i) u.t[i] = in[i];
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) p[k] = u.v[k];
+    }
+};
+
+static constexpr int kBlock = 256;        // 4 waves per workgroup
+static constexpr int kReduceBlocks = 1024;  // grid cap of the reducing kernels (4 per CU)
+
+static inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
+
+// ----------------------------------------------------------------------------------------------
+// pointwise kernels
+// ----------------------------------------------------------------------------------------------
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_affine(S sys, const T* __restrict__ x, T* __restrict__ f1,
+                                                   T* __restrict__ f2, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], a[S::N], b[S::N * S::M];
+    RowIO<T, S::N>::load(x, i, xs);
+    sys.affine(xs, a, b);
+    RowIO<T, S::N>::store(f1, i, a);
+    RowIO<T, S::N * S::M>::store(f2, i, b);
+}
+
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_wrap(S sys, const T* x, T* out, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N];
+    RowIO<T, S::N>::load(x, i, xs);
+    sys.wrap(xs);
+    RowIO<T, S::N>::store(out, i, xs);
+}
+
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_xdot(S sys, const T* __restrict__ x, const T* __restrict__ u,
+                                                 T* __restrict__ xd, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], us[S::M], d[S::N];
+    RowIO<T, S::N>::load(x, i, xs);
+    RowIO<T, S::M>::load(u, i, us);
+    // f1 + f2 @ u, evaluated like the reference (dynamics_basic.py:101-103)
+    T f1[S::N], f2[S::N * S::M];
+    sys.affine(xs, f1, f2);
+#pragma unroll
+    for (int r = 0; r < S::N; ++r) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < S::M; ++j) acc += f2[r * S::M + j] * us[j];
+        d[r] = f1[r] + acc;
+    }
+    RowIO<T, S::N>::store(xd, i, d);
+}
+
+template <int INTEG, typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_simulate(S sys, Limits<T, S::M> lim, const T* x, const T* __restrict__ u,
+                                                     T* xn, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], us[S::M], uc[S::M], o[S::N];
+    RowIO<T, S::N>::load(x, i, xs);
+    RowIO<T, S::M>::load(u, i, us);
+    clip_u<T, S::M>(lim, us, uc);
+    integrate<INTEG>(sys, lim.dt, xs, uc, o);
+    RowIO<T, S::N>::store(xn, i, o);
+}
+
+template <typename S, typename T> struct X0P { T mean[S::N], std[S::N]; };
+
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_initial_state(S sys, X0P<S, T> p, const T* __restrict__ u01,
+                                                          T* __restrict__ x0, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T r[S::N], o[S::N];
+    RowIO<T, S::N>::load(u01, i, r);
+#pragma unroll
+    for (int k = 0; k < S::N; ++k) {
+        const T lo = -p.std[k], hi = p.std[k];  // np.random.uniform(low, high): low + (high-low)*u
+        o[k] = (lo + (hi - lo) * r[k]) + p.mean[k];
+    }
+    sys.wrap(o);
+    RowIO<T, S::N>::store(x0, i, o);
+}
+
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_running_cost(S sys, TaskP<T, S::N, S::M> tk, const T* __restrict__ x,
+                                                         const T* __restrict__ u, T* __restrict__ cost, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], us[S::M], e[S::N];
+    RowIO<T, S::N>::load(x, i, xs);
+    RowIO<T, S::M>::load(u, i, us);
+    error_coords(sys, tk.xf, xs, e);
+    cost[i] = running_cost_e<S, T>(tk, e, us);
+}
+
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_termination_cost(S sys, TaskP<T, S::N, S::M> tk, const T* __restrict__ x,
+                                                             T* __restrict__ cost, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], e[S::N];
+    RowIO<T, S::N>::load(x, i, xs);
+    error_coords(sys, tk.xf, xs, e);
+    cost[i] = quad_form<S::N>(tk.P, e);
+}
+
+template <typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_control_from_grad(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim,
+                                                              const T* __restrict__ x, const T* __restrict__ g,
+                                                              T* __restrict__ u, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], gs[S::N], f1[S::N], f2[S::N * S::M], ur[S::M], uo[S::M];
+    RowIO<T, S::N>::load(x, i, xs);
+    RowIO<T, S::N>::load(g, i, gs);
+    sys.affine(xs, f1, f2);
+    control_from_grad<S, T>(tk, lim, f2, gs, ur, uo);
+    RowIO<T, S::M>::store(u, i, uo);
+}
+
+template <int CK, typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_controller(S sys, CtrlP<T, S::N, S::M> c, Limits<T, S::M> lim,
+                                                       const T* __restrict__ x, T* __restrict__ u, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[S::N], uo[S::M];
+    RowIO<T, S::N>::load(x, i, xs);
+    controller_eval<CK>(sys, c, lim, xs, uo);
+    RowIO<T, S::M>::store(u, i, uo);
+}
+
+// ----------------------------------------------------------------------------------------------
+// deterministic 3-way sum: lane partials (double) -> wave64 shuffle tree -> LDS across the 4 waves
+// -> one (3 x double) record per workgroup in the caller's workspace -> k_reduce_final sums the
+// records in index order.  No float atomics: results are bitwise reproducible run to run.
+// ----------------------------------------------------------------------------------------------
+HJBX_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+HJBX_DEV void block_sum3(double a, double b, double c, double* ws_record) {
+    __shared__ double lds[3][kBlock / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { lds[0][wave] = a; lds[1][wave] = b; lds[2][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { s0 += lds[0][w]; s1 += lds[1][w]; s2 += lds[2][w]; }
+        ws_record[0] = s0; ws_record[1] = s1; ws_record[2] = s2;
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(64) void k_reduce_final(const double* ws, int nrec, T* sums) {
+    double a = 0, b = 0, c = 0;
+    for (int r = threadIdx.x; r < nrec; r += 64) { a += ws[3 * r]; b += ws[3 * r + 1]; c += ws[3 * r + 2]; }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if (threadIdx.x == 0) { sums[0] = (T)a; sums[1] = (T)b; sums[2] = (T)c; }
+}
+
+// hjb_loss body (vhjb.py:227-241) + analytic d loss_i / d gradV
+template <int MODE, typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim,
+                                                         const T* __restrict__ x, const T* __restrict__ g,
+                                                         const T* __restrict__ done, T* __restrict__ loss_i,
+                                                         T* __restrict__ dl_dg, double* __restrict__ ws, int64_t B) {
+    constexpr int N = S::N, M = S::M;
+    double acc_l = 0, acc_nb = 0, acc_nd = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
+        T xs[N], gs[N], f1[N], f2[N * M], ur[M], u[M], e[N], xd[N];
+        RowIO<T, N>::load(x, i, xs);
+        RowIO<T, N>::load(g, i, gs);
+        const T dn = done[i];
+        sys.affine(xs, f1, f2);
+        control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
+        T vdot = T(0);
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            T a = T(0);
+#pragma unroll
+            for (int j = 0; j < M; ++j) a += f2[r * M + j] * u[j];
+            xd[r] = f1[r] + a;
+            vdot += gs[r] * xd[r];
+        }
+        error_coords(sys, tk.xf, xs, e);
+        const T l = running_cost_e<S, T>(tk, e, u);
+        const T den = l + tk.eps;
+        const T r = (MODE == 0) ? vdot / den + T(1) : vdot + l;
+        const T w = T(1) - dn;
+        const T li = abs_t(r) * w;
+        if (loss_i) loss_i[i] = li;
+        if (dl_dg) {
+            // du/dg = -1/2 D Rinv f2' ; dV./dg = xdot + (du/dg)' f2' g ; dl/dg = (du/dg)' (R+R')(u-uf)
+            T f2tg[M], rdu[M];
+            bool open[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                T a = T(0);
+#pragma unroll
+                for (int k = 0; k < N; ++k) a += f2[k * M + j] * gs[k];
+                f2tg[j] = a;
+                T b = T(0);
+#pragma unroll
+                for (int k = 0; k < M; ++k) b += (tk.R[j * M + k] + tk.R[k * M + j]) * (u[k] - tk.uf[k]);
+                rdu[j] = b;
+                open[j] = (ur[j] > lim.umin[j]) && (ur[j] < lim.umax[j]);
+            }
+            const T sg = (r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0));
+            T out[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                T dv = xd[k], dl = T(0);
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    T a = T(0);
+#pragma unroll
+                    for (int q = 0; q < M; ++q) a += tk.Rinv[j * M + q] * f2[k * M + q];
+                    const T dudg = open[j] ? -a / T(2) : T(0);
+                    dv += dudg * f2tg[j];
+                    dl += dudg * rdu[j];
+                }
+                const T dr = (MODE == 0) ? dv / den - vdot * dl / (den * den) : dv + dl;
+                out[k] = sg * w * dr;
+            }
+            RowIO<T, N>::store(dl_dg, i, out);
+        }
+        acc_l += (double)li;
+        acc_nb += (double)w;
+        acc_nd += (double)dn;
+    }
+    if (ws) block_sum3(acc_l, acc_nb, acc_nd, ws + 3 * blockIdx.x);
+}
+
+// termination_loss body (vhjb.py:243-253)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_termination_residual(T eps, const T* __restrict__ V, const T* __restrict__ cost,
+                                                                 const T* __restrict__ done, T* __restrict__ loss_i,
+                                                                 T* __restrict__ dl_dV, double* __restrict__ ws, int64_t B) {
+    double acc_l = 0, acc_nb = 0, acc_nd = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
+        const T dn = done[i];
+        const T den = cost[i] + eps;
+        const T r = V[i] / den - T(1);
+        const T li = abs_t(r) * dn;
+        if (loss_i) loss_i[i] = li;
+        if (dl_dV) dl_dV[i] = ((r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0))) * dn / den;
+        acc_l += (double)li;
+        acc_nb += 1.0 - (double)dn;
+        acc_nd += (double)dn;
+    }
+    if (ws) block_sum3(acc_l, acc_nb, acc_nd, ws + 3 * blockIdx.x);
+}
+
+// ----------------------------------------------------------------------------------------------
+// closed loop: one VHJB step given gradV, and whole rollouts under closed-form controllers
+// ----------------------------------------------------------------------------------------------
+template <int INTEG, typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim, int t, int T_max,
+                                                      const T* x, const T* __restrict__ g, T* xn, T* __restrict__ u_out,
+                                                      T* __restrict__ cost_t, T* __restrict__ done_t,
+                                                      int32_t* __restrict__ done_step, int64_t B) {
+    constexpr int N = S::N, M = S::M;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T xs[N], gs[N], xo[N], u[M];
+    RowIO<T, N>::load(x, i, xs);
+    RowIO<T, N>::load(g, i, gs);
+    const int32_t ds = done_step[i];
+#pragma unroll
+    for (int k = 0; k < N; ++k) xo[k] = xs[k];
+#pragma unroll
+    for (int j = 0; j < M; ++j) u[j] = T(0);
+    T c = T(0), d = T(0);
+    if (ds < 0) {
+        T e[N];
+        error_coords(sys, tk.xf, xs, e);
+        if (t >= T_max || out_of_box<S, T>(tk, e)) {  // vhjb.py:176-181 and 188-191
+            c = quad_form<N>(tk.P, e);
+            d = T(1);
+            done_step[i] = t;
+        } else {  // vhjb.py:183-186
+            T f1[N], f2[N * M], ur[M];
+            sys.affine(xs, f1, f2);
+            control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
+            c = running_cost_e<S, T>(tk, e, u) * lim.dt;
+            integrate<INTEG>(sys, lim.dt, xs, u, xo);
+        }
+    }
+    RowIO<T, N>::store(xn, i, xo);
+    if (u_out) RowIO<T, M>::store(u_out, i, u);
+    cost_t[i] = c;
+    done_t[i] = d;
+}
+
+template <int INTEG, int CK, typename S, typename T>
+__global__ __launch_bounds__(kBlock) void k_rollout_feedback(S sys, TaskP<T, S::N, S::M> tk, CtrlP<T, S::N, S::M> c,
+                                                             Limits<T, S::M> lim, uint32_t flags, int has_task, int T_steps,
+                                                             const T* __restrict__ x0, T* __restrict__ traj,
+                                                             T* __restrict__ u_log, T* __restrict__ cost,
+                                                             int32_t* __restrict__ done_step, T* __restrict__ total_cost,
+                                                             T* __restrict__ x_final, int64_t B) {
+    constexpr int N = S::N, M = S::M;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    T x[N], xn[N], u[M];
+    RowIO<T, N>::load(x0, i, x);
+    const bool term = (flags & HJBX_ROLLOUT_TERMINATE) != 0;
+    int ds = -1;
+    T tot = T(0);
+    for (int t = 0; t <= T_steps; ++t) {
+        if (traj) RowIO<T, N>::store(traj + (int64_t)t * B * N, i, x);
+        T cst = T(0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) u[j] = T(0);
+        if (ds < 0) {
+            T e[N];
+            bool oob = false;
+            if (has_task) {
+                error_coords(sys, tk.xf, x, e);
+                oob = term && out_of_box<S, T>(tk, e);
+            }
+            if (t == T_steps || oob) {
+                if (has_task && term) cst = quad_form<N>(tk.P, e);
+                ds = t;
+            } else {
+                controller_eval<CK>(sys, c, lim, x, u);
+                if (has_task) cst = running_cost_e<S, T>(tk, e, u) * lim.dt;
+                integrate<INTEG>(sys, lim.dt, x, u, xn);
+#pragma unroll
+                for (int k = 0; k < N; ++k) x[k] = xn[k];
+            }
+        }
+        tot += cst;
+        if (cost) cost[(int64_t)t * B + i] = cst;
+        if (u_log && t < T_steps) RowIO<T, M>::store(u_log + (int64_t)t * B * M, i, u);
+    }
+    if (done_step) done_step[i] = ds;
+    if (total_cost) total_cost[i] = tot;
+    if (x_final) RowIO<T, N>::store(x_final, i, x);
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side: descriptor conversion and dispatch
+// ----------------------------------------------------------------------------------------------
+template <typename T, int M> static Limits<T, M> make_limits(const hjbx_system* s) {
+    Limits<T, M> l;
+    for (int j = 0; j < M; ++j) { l.umin[j] = (T)s->umin[j]; l.umax[j] = (T)s->umax[j]; }
+    l.dt = (T)s->dt;
+    return l;
+}
+
+template <typename T, int N, int M> static TaskP<T, N, M> make_task(const hjbx_task* t) {
+    TaskP<T, N, M> k;
+    memset(&k, 0, sizeof(k));
+    if (!t) return k;
+    for (int i = 0; i < N * N; ++i) { k.Q[i] = (T)t->Q[i]; k.P[i] = (T)t->P[i]; }
+    for (int i = 0; i < M * M; ++i) { k.R[i] = (T)t->R[i]; k.Rinv[i] = (T)t->Rinv[i]; }
+    for (int i = 0; i < N; ++i) { k.xf[i] = (T)t->xf[i]; k.omin[i] = (T)t->obs_min[i]; k.omax[i] = (T)t->obs_max[i]; }
+    for (int j = 0; j < M; ++j) k.uf[j] = (T)t->uf[j];
+    k.eps = (T)t->eps;
+    return k;
+}
+
+template <typename T, int N, int M> static CtrlP<T, N, M> make_ctrl(const hjbx_controller* c) {
+    CtrlP<T, N, M> k;
+    memset(&k, 0, sizeof(k));
+    k.wrap_error = c->wrap_error;
+    for (int i = 0; i < M * N; ++i) k.K[i] = (T)c->K[i];
+    for (int i = 0; i < N; ++i) k.xf[i] = (T)c->xf[i];
+    for (int j = 0; j < M; ++j) k.uf[j] = (T)c->uf[j];
+    for (int i = 0; i < N * N; ++i) k.P[i] = (T)c->P[i];
+    for (int i = 0; i < 3; ++i) k.Kes[i] = (T)c->Kes[i];
+    k.eps_energy = (T)c->eps_energy;
+    k.eps_state = (T)c->eps_state;
+    k.eps_region = (T)c->eps_region;
+    return k;
+}
+
+template <typename T, int N, int M> static Linear<T, N, M> make_linear(const hjbx_system* s) {
+    Linear<T, N, M> l;
+    for (int i = 0; i < N * N; ++i) l.A[i] = (T)s->p[i];
+    for (int i = 0; i < N * M; ++i) l.Bm[i] = (T)s->p[N * N + i];
+    return l;
+}
+
+// Calls f(system_pod) with the concrete device system type for this handle; false if unsupported.
+template <typename T, typename F> static bool with_system(const hjbx_system* s, F&& f) {
+    switch (s->kind) {
+    case HJBX_SYS_LINEAR:
+        if (s->n == 2 && s->m == 1) { f(make_linear<T, 2, 1>(s)); return true; }
+        if (s->n == 2 && s->m == 2) { f(make_linear<T, 2, 2>(s)); return true; }
+        if (s->n == 4 && s->m == 1) { f(make_linear<T, 4, 1>(s)); return true; }
+        if (s->n == 4 && s->m == 2) { f(make_linear<T, 4, 2>(s)); return true; }
+        if (s->n == 6 && s->m == 2) { f(make_linear<T, 6, 2>(s)); return true; }
+        return false;
+    case HJBX_SYS_CARTPOLE: { Cartpole<T> c{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(c); return true; }
+    case HJBX_SYS_ACROBOT: {
+        Acrobot<T> a{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3], (T)s->p[4], (T)s->p[5], (T)s->p[6]};
+        f(a); return true;
+    }
+    case HJBX_SYS_QUAD2D: { Quad2D<T> q{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(q); return true; }
+    case HJBX_SYS_NEARHOVER: { NearHover<T> q{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(q); return true; }
+    }
+    return false;
+}
+
+static int unsupported(const hjbx_system* s) {
+    return hjbx_set_error(HJBX_EUNSUPPORTED, "no kernel for system kind %d with n=%d m=%d", s->kind, s->n, s->m);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// a (B, cols) row-major buffer is accessed with RowIO's vector width: 16, 8 or 4 bytes
+static bool aligned_rows(const void* p, size_t row_bytes) {
+    const uintptr_t a = (row_bytes % 16 == 0) ? 15u : (row_bytes % 8 == 0) ? 7u : 3u;
+    return (reinterpret_cast<uintptr_t>(p) & a) == 0;
+}
+
+#define HJBX_CHECK_COMMON(sys, B)                                                   \
+    HJBX_REQUIRE((sys) != nullptr, "system handle is NULL");                        \
+    HJBX_REQUIRE((B) >= 0, "negative batch size %lld", (long long)(B));             \
+    if ((B) == 0) return HJBX_OK;
+
+// ROWS(p, cols): non-NULL (B, cols) buffer of T aligned for its row vector width; OPT: may be NULL
+#define HJBX_CHECK_ROWS(p, cols) \
+    HJBX_REQUIRE((p) != nullptr && aligned_rows(p, (size_t)(cols) * sizeof(T)), #p " must be a non-NULL device pointer aligned to its row vector width")
+#define HJBX_CHECK_OPT(p, cols) \
+    HJBX_REQUIRE((p) == nullptr || aligned_rows(p, (size_t)(cols) * sizeof(T)), #p " must be aligned to its row vector width")
+
+// ---- typed implementations ---------------------------------------------------------------------
+template <typename T> static int affine_impl(const hjbx_system* sys, const T* x, T* f1, T* f2, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(f1, sys->n); HJBX_CHECK_ROWS(f2, sys->n * sys->m);
+    if (!with_system<T>(sys, [&](auto S) {
+            hipLaunchKernelGGL((k_affine<decltype(S), T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, x, f1, f2, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_affine");
+}
+
+template <typename T> static int wrap_impl(const hjbx_system* sys, const T* x, T* out, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(out, sys->n);
+    if (!with_system<T>(sys, [&](auto S) {
+            hipLaunchKernelGGL((k_wrap<decltype(S), T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, x, out, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_wrap");
+}
+
+template <typename T> static int xdot_impl(const hjbx_system* sys, const T* x, const T* u, T* xd, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(xd, sys->n);
+    if (!with_system<T>(sys, [&](auto S) {
+            hipLaunchKernelGGL((k_xdot<decltype(S), T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, x, u, xd, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_dynamics_step");
+}
+
+template <typename T>
+static int simulate_impl(const hjbx_system* sys, int integ, const T* x, const T* u, T* xn, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(xn, sys->n);
+    HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            auto lim = make_limits<T, SS::M>(sys);
+            if (integ == HJBX_EULER)
+                hipLaunchKernelGGL((k_simulate<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
+            else
+                hipLaunchKernelGGL((k_simulate<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_simulate");
+}
+
+template <typename T>
+static int initial_state_impl(const hjbx_system* sys, const double* mean, const double* sd, const T* u01, T* x0, int64_t B,
+                              void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(u01, sys->n); HJBX_CHECK_ROWS(x0, sys->n);
+    HJBX_REQUIRE(mean && sd, "x0_mean / x0_std are NULL");
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            X0P<SS, T> p;
+            for (int i = 0; i < SS::N; ++i) { p.mean[i] = (T)mean[i]; p.std[i] = (T)sd[i]; }
+            hipLaunchKernelGGL((k_initial_state<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, p, u01, x0, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_initial_state");
+}
+
+template <typename T>
+static int running_cost_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, const T* u, T* cost, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL"); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(cost, 1);
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            hipLaunchKernelGGL((k_running_cost<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
+                               make_task<T, SS::N, SS::M>(task), x, u, cost, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_running_cost");
+}
+
+template <typename T>
+static int termination_cost_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, T* cost, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL"); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(cost, 1);
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            hipLaunchKernelGGL((k_termination_cost<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
+                               make_task<T, SS::N, SS::M>(task), x, cost, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_termination_cost");
+}
+
+template <typename T>
+static int control_from_grad_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, const T* g, T* u, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL"); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(u, sys->m);
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            hipLaunchKernelGGL((k_control_from_grad<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
+                               make_task<T, SS::N, SS::M>(task), make_limits<T, SS::M>(sys), x, g, u, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_control_from_grad");
+}
+
+static inline int reduce_grid(int64_t B) {
+    int64_t g = (B + kBlock - 1) / kBlock;
+    return (int)(g < kReduceBlocks ? g : kReduceBlocks);
+}
+
+template <typename T>
+static int hjb_residual_impl(const hjbx_system* sys, const hjbx_task* task, int mode, const T* x, const T* g, const T* done,
+                             T* loss_i, T* dl_dg, T* sums, void* workspace, int64_t B, void* st) {
+    HJBX_REQUIRE(sys != nullptr, "system handle is NULL");
+    HJBX_REQUIRE(B >= 0, "negative batch size");
+    HJBX_REQUIRE(task, "task is NULL");
+    HJBX_REQUIRE(mode == HJBX_RESIDUAL_NORMALISED || mode == HJBX_RESIDUAL_RAW, "unknown residual mode %d", mode);
+    HJBX_REQUIRE(!sums || (workspace && aligned16(workspace)), "sums requested but workspace is NULL/unaligned");
+    if (B == 0) {
+        if (sums) {
+            hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(T), (hipStream_t)st);
+            if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        return HJBX_OK;
+    }
+    HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(done, 1); HJBX_CHECK_OPT(loss_i, 1); HJBX_CHECK_OPT(dl_dg, sys->n);
+    const int grid = reduce_grid(B);
+    double* ws = sums ? (double*)workspace : nullptr;
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            auto tk = make_task<T, SS::N, SS::M>(task);
+            auto lim = make_limits<T, SS::M>(sys);
+            if (mode == HJBX_RESIDUAL_NORMALISED)
+                hipLaunchKernelGGL((k_hjb_residual<0, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g,
+                                   done, loss_i, dl_dg, ws, B);
+            else
+                hipLaunchKernelGGL((k_hjb_residual<1, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g,
+                                   done, loss_i, dl_dg, ws, B);
+        })) return unsupported(sys);
+    if (sums) hipLaunchKernelGGL((k_reduce_final<T>), dim3(1), dim3(64), 0, (hipStream_t)st, ws, grid, sums);
+    return check_launch("hjbx_hjb_residual");
+}
+
+template <typename T>
+static int termination_residual_impl(double eps, const T* V, const T* cost, const T* done, T* loss_i, T* dl_dV, T* sums,
+                                     void* workspace, int64_t B, void* st) {
+    HJBX_REQUIRE(B >= 0, "negative batch size");
+    HJBX_REQUIRE(!sums || (workspace && aligned16(workspace)), "sums requested but workspace is NULL/unaligned");
+    if (B == 0) {
+        if (sums) {
+            hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(T), (hipStream_t)st);
+            if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        return HJBX_OK;
+    }
+    HJBX_REQUIRE(V && cost && done, "V/cost/done must be non-NULL");
+    const int grid = reduce_grid(B);
+    double* ws = sums ? (double*)workspace : nullptr;
+    hipLaunchKernelGGL((k_termination_residual<T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, (T)eps, V, cost, done,
+                       loss_i, dl_dV, ws, B);
+    if (sums) hipLaunchKernelGGL((k_reduce_final<T>), dim3(1), dim3(64), 0, (hipStream_t)st, ws, grid, sums);
+    return check_launch("hjbx_termination_residual");
+}
+
+template <typename T>
+static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int integ, int t, int T_max, const T* x, const T* g,
+                          T* xn, T* u_out, T* cost_t, T* done_t, int32_t* done_step, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL");
+    HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
+    HJBX_REQUIRE(t >= 0 && T_max >= 0, "negative step index");
+    HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(xn, sys->n); HJBX_CHECK_OPT(u_out, sys->m);
+    HJBX_REQUIRE(cost_t && done_t && done_step, "cost_t/done_t/done_step must be non-NULL");
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            auto tk = make_task<T, SS::N, SS::M>(task);
+            auto lim = make_limits<T, SS::M>(sys);
+            if (integ == HJBX_EULER)
+                hipLaunchKernelGGL((k_vhjb_step<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
+                                   g, xn, u_out, cost_t, done_t, done_step, B);
+            else
+                hipLaunchKernelGGL((k_vhjb_step<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
+                                   g, xn, u_out, cost_t, done_t, done_step, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_vhjb_step");
+}
+
+template <typename S> struct is_cartpole { static constexpr bool value = false; };
+template <typename T> struct is_cartpole<Cartpole<T>> { static constexpr bool value = true; };
+template <typename S> struct is_acrobot { static constexpr bool value = false; };
+template <typename T> struct is_acrobot<Acrobot<T>> { static constexpr bool value = true; };
+
+static int check_ctrl(const hjbx_system* sys, const hjbx_controller* c) {
+    HJBX_REQUIRE(c, "controller is NULL");
+    HJBX_REQUIRE(c->kind >= HJBX_CTRL_LINEAR_FEEDBACK && c->kind <= HJBX_CTRL_ACROBOT_ENERGY, "unknown controller kind %d", c->kind);
+    if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY && sys->kind != HJBX_SYS_CARTPOLE)
+        return hjbx_set_error(HJBX_EINVAL, "cartpole energy-shaping controller needs a cartpole system");
+    if (c->kind == HJBX_CTRL_ACROBOT_ENERGY && sys->kind != HJBX_SYS_ACROBOT)
+        return hjbx_set_error(HJBX_EINVAL, "acrobot energy-shaping controller needs an acrobot system");
+    return HJBX_OK;
+}
+
+template <typename T>
+static int controller_impl(const hjbx_system* sys, const hjbx_controller* c, const T* x, T* u, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B);
+    if (int rc = check_ctrl(sys, c)) return rc;
+    HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m);
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            auto cp = make_ctrl<T, SS::N, SS::M>(c);
+            auto lim = make_limits<T, SS::M>(sys);
+            if constexpr (is_cartpole<SS>::value) {
+                if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY) {
+                    hipLaunchKernelGGL((k_controller<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, cp, lim, x, u, B);
+                    return;
+                }
+            }
+            if constexpr (is_acrobot<SS>::value) {
+                if (c->kind == HJBX_CTRL_ACROBOT_ENERGY) {
+                    hipLaunchKernelGGL((k_controller<2, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, cp, lim, x, u, B);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((k_controller<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, cp, lim, x, u, B);
+        })) return unsupported(sys);
+    return check_launch("hjbx_controller");
+}
+
+template <int INTEG, typename SS, typename T>
+static void launch_rollout(const hjbx_system* sys, SS S, const hjbx_task* task, const hjbx_controller* c, uint32_t flags,
+                           int T_steps, const T* x0, T* traj, T* u_log, T* cost, int32_t* done_step, T* total_cost, T* x_final,
+                           int64_t B, void* st) {
+    auto tk = make_task<T, SS::N, SS::M>(task);
+    auto cp = make_ctrl<T, SS::N, SS::M>(c);
+    auto lim = make_limits<T, SS::M>(sys);
+    const int has_task = task != nullptr;
+#define HJBX_LAUNCH_RO(CK)                                                                                                    \
+    hipLaunchKernelGGL((k_rollout_feedback<INTEG, CK, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, cp, lim, \
+                       flags, has_task, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B)
+    if constexpr (is_cartpole<SS>::value) {
+        if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY) { HJBX_LAUNCH_RO(1); return; }
+    }
+    if constexpr (is_acrobot<SS>::value) {
+        if (c->kind == HJBX_CTRL_ACROBOT_ENERGY) { HJBX_LAUNCH_RO(2); return; }
+    }
+    HJBX_LAUNCH_RO(0);
+#undef HJBX_LAUNCH_RO
+}
+
+template <typename T>
+static int rollout_feedback_impl(const hjbx_system* sys, const hjbx_task* task, const hjbx_controller* c, int integ, uint32_t flags,
+                                 int T_steps, const T* x0, T* traj, T* u_log, T* cost, int32_t* done_step, T* total_cost,
+                                 T* x_final, int64_t B, void* st) {
+    HJBX_CHECK_COMMON(sys, B);
+    if (int rc = check_ctrl(sys, c)) return rc;
+    HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
+    HJBX_REQUIRE(T_steps >= 0, "negative horizon");
+    HJBX_REQUIRE((flags & ~HJBX_ROLLOUT_TERMINATE) == 0, "unknown rollout flags 0x%x", flags);
+    HJBX_REQUIRE(task || !(flags & HJBX_ROLLOUT_TERMINATE), "HJBX_ROLLOUT_TERMINATE needs a task");
+    HJBX_REQUIRE(task || (!cost && !total_cost), "cost outputs need a task");
+    HJBX_CHECK_ROWS(x0, sys->n); HJBX_CHECK_OPT(traj, sys->n); HJBX_CHECK_OPT(u_log, sys->m); HJBX_CHECK_OPT(x_final, sys->n);
+    if (!with_system<T>(sys, [&](auto S) {
+            using SS = decltype(S);
+            if (integ == HJBX_EULER)
+                launch_rollout<0, SS, T>(sys, S, task, c, flags, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B, st);
+            else
+                launch_rollout<1, SS, T>(sys, S, task, c, flags, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B, st);
+        })) return unsupported(sys);
+    return check_launch("hjbx_rollout_feedback");
+}
+
+// ----------------------------------------------------------------------------------------------
+// extern "C" surface
+// ----------------------------------------------------------------------------------------------
+extern "C" {
+
+int hjbx_version(void) { return HJBX_VERSION; }
+
+size_t hjbx_last_error(char* buf, size_t buflen) {
+    const size_t len = strlen(g_err);
+    if (buf && buflen) {
+        const size_t ncopy = len < buflen - 1 ? len : buflen - 1;
+        memcpy(buf, g_err, ncopy);
+        buf[ncopy] = '\0';
+    }
+    return len;
+}
+
+int hjbx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+size_t hjbx_reduce_workspace_bytes(void) { return (size_t)kReduceBlocks * 3 * sizeof(double); }
+
+int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, const double* umax, const double* params,
+                       int n_params, hjbx_system** out) {
+    HJBX_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    HJBX_REQUIRE(umin && umax && params, "umin/umax/params must be non-NULL");
+    HJBX_REQUIRE(dt > 0 && std::isfinite(dt), "dt must be positive and finite");
+    int en = 0, em = 0, ep = 0;
+    switch (kind) {
+    case HJBX_SYS_LINEAR:
+        HJBX_REQUIRE(n >= 1 && n <= HJBX_MAX_N && m >= 1 && m <= HJBX_MAX_M, "linear system needs 1<=n<=%d, 1<=m<=%d", HJBX_MAX_N, HJBX_MAX_M);
+        en = n; em = m; ep = n * n + n * m; break;
+    case HJBX_SYS_CARTPOLE: en = 4; em = 1; ep = 4; break;
+    case HJBX_SYS_ACROBOT: en = 4; em = 1; ep = 7; break;
+    case HJBX_SYS_QUAD2D: en = 6; em = 2; ep = 4; break;
+    case HJBX_SYS_NEARHOVER: en = 10; em = 3; ep = 4; break;
+    default: return hjbx_set_error(HJBX_EINVAL, "unknown system kind %d", kind);
+    }
+    HJBX_REQUIRE(n == en && m == em, "system kind %d has n=%d m=%d, got n=%d m=%d", kind, en, em, n, m);
+    HJBX_REQUIRE(n_params == ep, "system kind %d takes %d parameters, got %d", kind, ep, n_params);
+    for (int j = 0; j < m; ++j) HJBX_REQUIRE(umin[j] <= umax[j], "umin[%d] > umax[%d]", j, j);
+    hjbx_system* s = new (std::nothrow) hjbx_system();
+    if (!s) return hjbx_set_error(HJBX_EINVAL, "out of host memory");
+    memset(s, 0, sizeof(*s));
+    s->kind = kind; s->n = n; s->m = m; s->dt = dt; s->n_params = n_params;
+    for (int j = 0; j < m; ++j) { s->umin[j] = umin[j]; s->umax[j] = umax[j]; }
+    for (int i = 0; i < n_params; ++i) s->p[i] = params[i];
+    *out = s;
+    return HJBX_OK;
+}
+
+void hjbx_system_destroy(hjbx_system* sys) { delete sys; }
+
+int hjbx_dims(const hjbx_system* sys, int* n, int* m) {
+    HJBX_REQUIRE(sys && n && m, "NULL argument");
+    *n = sys->n; *m = sys->m;
+    return HJBX_OK;
+}
+
+#define HJBX_DEFINE(T, SFX)                                                                                                   \
+    int hjbx_affine_##SFX(const hjbx_system* s, const T* x, T* f1, T* f2, int64_t B, void* st) { return affine_impl<T>(s, x, f1, f2, B, st); } \
+    int hjbx_wrap_##SFX(const hjbx_system* s, const T* x, T* o, int64_t B, void* st) { return wrap_impl<T>(s, x, o, B, st); }  \
+    int hjbx_dynamics_step_##SFX(const hjbx_system* s, const T* x, const T* u, T* xd, int64_t B, void* st) { return xdot_impl<T>(s, x, u, xd, B, st); } \
+    int hjbx_simulate_##SFX(const hjbx_system* s, int integ, const T* x, const T* u, T* xn, int64_t B, void* st) { return simulate_impl<T>(s, integ, x, u, xn, B, st); } \
+    int hjbx_initial_state_##SFX(const hjbx_system* s, const double* mean, const double* sd, const T* u01, T* x0, int64_t B, void* st) { return initial_state_impl<T>(s, mean, sd, u01, x0, B, st); } \
+    int hjbx_running_cost_##SFX(const hjbx_system* s, const hjbx_task* t, const T* x, const T* u, T* c, int64_t B, void* st) { return running_cost_impl<T>(s, t, x, u, c, B, st); } \
+    int hjbx_termination_cost_##SFX(const hjbx_system* s, const hjbx_task* t, const T* x, T* c, int64_t B, void* st) { return termination_cost_impl<T>(s, t, x, c, B, st); } \
+    int hjbx_control_from_grad_##SFX(const hjbx_system* s, const hjbx_task* t, const T* x, const T* g, T* u, int64_t B, void* st) { return control_from_grad_impl<T>(s, t, x, g, u, B, st); } \
+    int hjbx_hjb_residual_##SFX(const hjbx_system* s, const hjbx_task* t, int mode, const T* x, const T* g, const T* done, T* li, T* dg, T* sums, void* ws, int64_t B, void* st) { return hjb_residual_impl<T>(s, t, mode, x, g, done, li, dg, sums, ws, B, st); } \
+    int hjbx_termination_residual_##SFX(double eps, const T* V, const T* cost, const T* done, T* li, T* dV, T* sums, void* ws, int64_t B, void* st) { return termination_residual_impl<T>(eps, V, cost, done, li, dV, sums, ws, B, st); } \
+    int hjbx_vhjb_step_##SFX(const hjbx_system* s, const hjbx_task* t, int integ, int step, int T_max, const T* x, const T* g, T* xn, T* uo, T* c, T* d, int32_t* ds, int64_t B, void* st) { return vhjb_step_impl<T>(s, t, integ, step, T_max, x, g, xn, uo, c, d, ds, B, st); } \
+    int hjbx_controller_##SFX(const hjbx_system* s, const hjbx_controller* c, const T* x, T* u, int64_t B, void* st) { return controller_impl<T>(s, c, x, u, B, st); } \
+    int hjbx_rollout_feedback_##SFX(const hjbx_system* s, const hjbx_task* t, const hjbx_controller* c, int integ, uint32_t flags, int T_steps, const T* x0, T* traj, T* ul, T* cost, int32_t* ds, T* tc, T* xf, int64_t B, void* st) { return rollout_feedback_impl<T>(s, t, c, integ, flags, T_steps, x0, traj, ul, cost, ds, tc, xf, B, st); }
+
+HJBX_DEFINE(float, f32)
+HJBX_DEFINE(double, f64)
+
+}  // extern "C"

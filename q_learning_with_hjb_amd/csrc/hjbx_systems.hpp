@@ -1,0 +1,387 @@
+// hjbx_systems.hpp -- per-environment device math for the five control-affine systems (gfx950).
+//
+// Every system is a POD passed BY VALUE as a kernel argument (kernarg segment -> scalar loads into
+// SGPRs, uniform across the wave), with compile-time state/control dimensions so a state vector
+// lives in VGPRs and all loops unroll.  One lane = one environment.
+//
+// The manipulator systems use algebraically reduced closed forms (no 2x2 inverse); the CPU oracle
+// keeps the reference's M/C/G + inverse structure, so agreement between the two is a real check.
+// Reference statements restated here are cited per function (paths under the reference repo).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hjbx {
+
+#define HJBX_DEV __device__ __forceinline__
+
+template <typename T> struct Const;
+template <> struct Const<float> {
+    static constexpr float pi = 3.14159274101257324219f;      // float32(np.pi)
+    static constexpr float two_pi = 6.28318548202514648438f;  // float32(2*np.pi)
+};
+template <> struct Const<double> {
+    static constexpr double pi = 3.14159265358979311600;
+    static constexpr double two_pi = 6.28318530717958623200;
+};
+
+HJBX_DEV void sincos_t(float a, float* s, float* c) { sincosf(a, s, c); }   // precise (ocml), not v_sin_f32
+HJBX_DEV void sincos_t(double a, double* s, double* c) { sincos(a, s, c); }
+HJBX_DEV float tan_t(float a) { return tanf(a); }
+HJBX_DEV double tan_t(double a) { return tan(a); }
+HJBX_DEV float fmod_t(float a, float b) { return fmodf(a, b); }
+HJBX_DEV double fmod_t(double a, double b) { return fmod(a, b); }
+HJBX_DEV float sqrt_t(float a) { return sqrtf(a); }
+HJBX_DEV double sqrt_t(double a) { return sqrt(a); }
+HJBX_DEV float abs_t(float a) { return fabsf(a); }
+HJBX_DEV double abs_t(double a) { return fabs(a); }
+
+// np.remainder(th + pi, 2 pi) - pi  (cartpole.py:61-63, quadrotors.py:67-69,167-169, acrobot.py:78-79).
+// NumPy's remainder is fmod followed by a shift into [0, b); fmod is exact, and for |a| < 2b it is
+// a, a-b (exact by Sterbenz) or a (then +b), so the three fast branches are bit-identical to it.
+template <typename T> HJBX_DEV T wrap_angle(T th) {
+    constexpr T pi = Const<T>::pi, b = Const<T>::two_pi;
+    const T a = th + pi;
+    T r;
+    if (a >= T(0) && a < b) r = a;
+    else if (a >= b && a < T(2) * b) r = a - b;
+    else if (a < T(0) && a >= -b) r = a + b;
+    else {
+        r = fmod_t(a, b);
+        if (r != T(0)) { if (r < T(0)) r += b; } else r = T(0);
+    }
+    return r - pi;
+}
+
+template <typename T> HJBX_DEV T clamp_t(T v, T lo, T hi) {  // np.clip: min(max(v, lo), hi)
+    v = v < lo ? lo : v;
+    v = v > hi ? hi : v;
+    return v;
+}
+
+// ---- Linear: dynamics/linear.py:7-22 --------------------------------------------------------------
+template <typename T, int N_, int M_> struct Linear {
+    static constexpr int N = N_, M = M_;
+    T A[N * N], Bm[N * M];
+    HJBX_DEV void wrap(T*) const {}
+    HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += A[i * N + j] * x[j];
+            f1[i] = acc;
+#pragma unroll
+            for (int j = 0; j < M; ++j) f2[i * M + j] = Bm[i * M + j];
+        }
+    }
+    HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += A[i * N + j] * x[j];
+            T bu = T(0);
+#pragma unroll
+            for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+            xd[i] = acc + bu;
+        }
+    }
+};
+
+// ---- Cartpole: dynamics/cartpole.py:19-64 through dynamics_basic.py:64-94 -------------------------
+// D = mc + mp s^2;  f1 = [xd, thd, (mp l thd^2 s + mp g s c)/D, -(mp l thd^2 s c + (mc+mp) g s)/(l D)]
+// f2 = [0, 0, 1/D, -c/(l D)]      (theta = pi is upright)
+template <typename T> struct Cartpole {
+    static constexpr int N = 4, M = 1;
+    T mc, mp, l, g;
+    HJBX_DEV void wrap(T* x) const { x[1] = wrap_angle(x[1]); }
+    HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
+        T s, c;
+        sincos_t(x[1], &s, &c);
+        const T invD = T(1) / (mc + mp * s * s);
+        const T w = mp * l * x[3] * x[3] * s;
+        f1[0] = x[2];
+        f1[1] = x[3];
+        f1[2] = (w + mp * g * s * c) * invD;
+        f1[3] = -(w * c + (mc + mp) * g * s) * invD / l;
+        f2[0] = T(0);
+        f2[1] = T(0);
+        f2[2] = invD;
+        f2[3] = -c * invD / l;
+    }
+    HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
+        T f1[4], f2[4];
+        affine(x, f1, f2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xd[i] = f1[i] + f2[i] * u[0];
+    }
+};
+
+// ---- Acrobot: dynamics/acrobot.py:39-81 (constructor is stale upstream; math only) -----------------
+template <typename T> struct Acrobot {
+    static constexpr int N = 4, M = 1;
+    T m1, m2, l1, l2, I1, I2, g;
+    HJBX_DEV void wrap(T* x) const { x[0] = wrap_angle(x[0]); x[1] = wrap_angle(x[1]); }
+    // M = [[a, b],[b, d]], h = C qd + G
+    HJBX_DEV void mch(const T* x, T& a, T& b, T& d, T& h0, T& h1) const {
+        T s1, c1, s2, c2, s12, c12;
+        sincos_t(x[0], &s1, &c1);
+        sincos_t(x[1], &s2, &c2);
+        sincos_t(x[0] + x[1], &s12, &c12);
+        const T k = m2 * l1 * l2 / T(2);
+        a = I1 + I2 + m2 * l1 * l1 + T(2) * k * c2;
+        b = I2 + k * c2;
+        d = I2;
+        const T G0 = (m1 * l1 / T(2) + m2 * l1) * g * s1 + m2 * g * l2 / T(2) * s12;
+        const T G1 = m2 * g * l2 / T(2) * s12;
+        h0 = (-T(2) * k * s2 * x[3]) * x[2] + (-k * s2 * x[3]) * x[3] + G0;
+        h1 = (k * s2 * x[2]) * x[2] + G1;
+    }
+    HJBX_DEV T energy(const T* x) const {  // acrobot.py:61-70
+        T s1, c1, s2, c2, s12, c12;
+        sincos_t(x[0], &s1, &c1);
+        sincos_t(x[1], &s2, &c2);
+        sincos_t(x[0] + x[1], &s12, &c12);
+        const T k = m2 * l1 * l2 / T(2);
+        const T T1 = T(0.5) * I1 * x[2] * x[2];
+        const T T2 = T(0.5) * (m2 * l1 * l1 + I2 + T(2) * k * c2) * x[2] * x[2] + T(0.5) * I2 * x[3] * x[3] +
+                     (I2 + k * c2) * x[2] * x[3];
+        const T U = -m1 * g * l1 / T(2) * c1 - m2 * g * (l1 * c1 + l2 / T(2) * c12);
+        return T1 + T2 + U;
+    }
+    HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
+        T a, b, d, h0, h1;
+        mch(x, a, b, d, h0, h1);
+        const T idet = T(1) / (a * d - b * b);
+        f1[0] = x[2];
+        f1[1] = x[3];
+        f1[2] = -(d * h0 - b * h1) * idet;
+        f1[3] = -(-b * h0 + a * h1) * idet;
+        f2[0] = T(0);
+        f2[1] = T(0);
+        f2[2] = -b * idet;  // Minv @ [0,1]
+        f2[3] = a * idet;
+    }
+    HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
+        T f1[4], f2[4];
+        affine(x, f1, f2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xd[i] = f1[i] + f2[i] * u[0];
+    }
+};
+
+// ---- Quadrotors2D: dynamics/quadrotors.py:17-70 ---------------------------------------------------
+template <typename T> struct Quad2D {
+    static constexpr int N = 6, M = 2;
+    T m, r, I, g;
+    HJBX_DEV void wrap(T* x) const { x[2] = wrap_angle(x[2]); }
+    HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
+        T s, c;
+        sincos_t(x[2], &s, &c);
+        f1[0] = x[3]; f1[1] = x[4]; f1[2] = x[5]; f1[3] = T(0); f1[4] = -g; f1[5] = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) f2[i] = T(0);
+        f2[6] = -s / m; f2[7] = -s / m;
+        f2[8] = c / m;  f2[9] = c / m;
+        f2[10] = r / I; f2[11] = -r / I;
+    }
+    HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
+        T s, c;
+        sincos_t(x[2], &s, &c);
+        const T ut = u[0] + u[1];
+        xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
+        xd[3] = T(0) + ((-s / m) * u[0] + (-s / m) * u[1]);
+        xd[4] = -g + ((c / m) * u[0] + (c / m) * u[1]);
+        xd[5] = T(0) + ((r / I) * u[0] + (-r / I) * u[1]);
+        (void)ut;
+    }
+};
+
+// ---- NearHoverQuadcopter: dynamics/quadrotors.py:118-170 ------------------------------------------
+template <typename T> struct NearHover {
+    static constexpr int N = 10, M = 3;
+    T g, m, kT, n0;
+    HJBX_DEV void wrap(T* x) const { x[3] = wrap_angle(x[3]); x[4] = wrap_angle(x[4]); }
+    HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) f1[i] = x[5 + i];
+        f1[5] = g * tan_t(x[3]); f1[6] = g * tan_t(x[4]); f1[7] = -g; f1[8] = T(0); f1[9] = T(0);
+#pragma unroll
+        for (int i = 0; i < 30; ++i) f2[i] = T(0);
+        f2[21] = kT / m; f2[25] = n0; f2[29] = n0;
+    }
+    HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) xd[i] = x[5 + i];
+        xd[5] = g * tan_t(x[3]);
+        xd[6] = g * tan_t(x[4]);
+        xd[7] = -g + (kT / m) * u[0];
+        xd[8] = n0 * u[1];
+        xd[9] = n0 * u[2];
+    }
+};
+
+// ---- shared per-environment pieces ---------------------------------------------------------------
+template <typename T, int M> struct Limits { T umin[M], umax[M], dt; };
+
+template <typename T, int N, int M> struct TaskP {
+    T Q[N * N], R[M * M], Rinv[M * M], P[N * N], xf[N], uf[M], omin[N], omax[N], eps;
+};
+
+template <typename T, int N, int M> struct CtrlP {
+    int wrap_error;
+    T K[M * N], xf[N], uf[M], P[N * N], Kes[3], eps_energy, eps_state, eps_region;
+};
+
+template <typename T, int M> HJBX_DEV void clip_u(const Limits<T, M>& lim, const T* u, T* uc) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) uc[j] = clamp_t(u[j], lim.umin[j], lim.umax[j]);
+}
+
+// Dynamics.simulate body after the clip (dynamics_basic.py:120); RK4 is this library's extension.
+template <int INTEG, typename S, typename T> HJBX_DEV void integrate(const S& sys, T dt, const T* x, const T* u, T* xn) {
+    constexpr int N = S::N;
+    T k1[N];
+    sys.xdot(x, u, k1);
+    if constexpr (INTEG == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) xn[i] = x[i] + k1[i] * dt;
+    } else {
+        T k2[N], k3[N], k4[N], xt[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + (dt / T(2)) * k1[i];
+        sys.xdot(xt, u, k2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + (dt / T(2)) * k2[i];
+        sys.xdot(xt, u, k3);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xt[i] = x[i] + dt * k3[i];
+        sys.xdot(xt, u, k4);
+#pragma unroll
+        for (int i = 0; i < N; ++i) xn[i] = x[i] + (dt / T(6)) * (k1[i] + T(2) * k2[i] + T(2) * k3[i] + k4[i]);
+    }
+    sys.wrap(xn);
+}
+
+// e = states_wrap(x - xf)  (vhjb.py:163, 168, 176)
+template <typename S, typename T> HJBX_DEV void error_coords(const S& sys, const T* xf, const T* x, T* e) {
+#pragma unroll
+    for (int i = 0; i < S::N; ++i) e[i] = x[i] - xf[i];
+    sys.wrap(e);
+}
+
+template <int N, typename T> HJBX_DEV T quad_form(const T* A, const T* v) {
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        T row = T(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j) row += A[i * N + j] * v[j];
+        acc += v[i] * row;
+    }
+    return acc;
+}
+
+// vhjb.py:220: u_raw = -Rinv f2' g / 2 + uf ; u = clip(u_raw)
+template <typename S, typename T>
+HJBX_DEV void control_from_grad(const TaskP<T, S::N, S::M>& tk, const Limits<T, S::M>& lim, const T* f2, const T* g,
+                                T* u_raw, T* u) {
+    constexpr int N = S::N, M = S::M;
+    T f2tg[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc += f2[i * M + j] * g[i];
+        f2tg[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < M; ++k) acc += tk.Rinv[j * M + k] * f2tg[k];
+        u_raw[j] = -acc / T(2) + tk.uf[j];
+    }
+    clip_u<T, M>(lim, u_raw, u);
+}
+
+// running cost given the error coordinates: e'Qe + (u-uf)'R(u-uf)   (vhjb.py:162-165)
+template <typename S, typename T>
+HJBX_DEV T running_cost_e(const TaskP<T, S::N, S::M>& tk, const T* e, const T* u) {
+    T du[S::M];
+#pragma unroll
+    for (int j = 0; j < S::M; ++j) du[j] = u[j] - tk.uf[j];
+    return quad_form<S::N>(tk.Q, e) + quad_form<S::M>(tk.R, du);
+}
+
+template <typename S, typename T> HJBX_DEV bool out_of_box(const TaskP<T, S::N, S::M>& tk, const T* e) {
+    bool out = false;  // strict compares, vhjb.py:176-177
+#pragma unroll
+    for (int i = 0; i < S::N; ++i) out = out || (e[i] > tk.omax[i]) || (e[i] < tk.omin[i]);
+    return out;
+}
+
+// ---- closed-form controllers -----------------------------------------------------------
+// CK = 0 linear feedback (lqr.py:25-26; quadrotors_model_based_controller.py:36-38, 73-75)
+// CK = 1 cartpole energy shaping (cartpole_energy_shaping.py:65-110), CK = 2 acrobot (acrobot_energy_shaping.py:74-121)
+template <int CK, typename S, typename T>
+HJBX_DEV void controller_eval(const S& sys, const CtrlP<T, S::N, S::M>& c, const Limits<T, S::M>& lim, const T* x, T* u) {
+    constexpr int N = S::N, M = S::M;
+    T ur[M];
+    if constexpr (CK == 0) {
+        T e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = x[i] - c.xf[i];
+        if (c.wrap_error) sys.wrap(e);
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc += c.K[j * N + i] * e[i];
+            ur[j] = -acc + c.uf[j];
+        }
+    } else if constexpr (CK == 1) {
+        T dx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dx[i] = x[i] - c.xf[i];
+        sys.wrap(dx);
+        T sth, cth, sf, cf;
+        sincos_t(x[1], &sth, &cth);
+        sincos_t(c.xf[1], &sf, &cf);
+        const T de = (T(0.5) * x[3] * x[3] - cth) - (T(0.5) * c.xf[3] * c.xf[3] - cf);
+        const T nrm = sqrt_t(dx[1] * dx[1] + dx[3] * dx[3]);
+        if (abs_t(de) < c.eps_energy && nrm < c.eps_state) {
+            T acc = T(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += c.K[i] * dx[i];
+            ur[0] = -acc;
+        } else {
+            const T u_bar = de * x[3] * cth;
+            const T ddq1 = c.Kes[0] * (-x[0]) + c.Kes[1] * (-x[2]) + c.Kes[2] * u_bar;
+            const T ddq2 = -cth / sys.l * ddq1 - sys.g * sth / sys.l;
+            ur[0] = (sys.mc + sys.mp) * ddq1 + sys.mp * sys.l * cth * ddq2 - sys.mp * sys.l * sth * x[3] * x[3];
+        }
+    } else {
+        T dx[4];
+        dx[0] = wrap_angle(x[0] - c.xf[0]);
+        dx[1] = wrap_angle(x[1] - c.xf[1]);
+        dx[2] = x[2] - c.xf[2];
+        dx[3] = x[3] - c.xf[3];
+        if (quad_form<4>(c.P, dx) < c.eps_region) {
+            T acc = T(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc += c.K[i] * dx[i];
+            ur[0] = -acc;
+        } else {
+            T a, b, d, h0, h1;
+            sys.mch(x, a, b, d, h0, h1);
+            const T ubar = (sys.energy(x) - sys.energy(c.xf)) * x[2];
+            const T ddq2 = c.Kes[0] * (-wrap_angle(x[1])) + c.Kes[1] * (-x[3]) + c.Kes[2] * ubar;
+            ur[0] = (d - b * b / a) * ddq2 + h1 - b / a * h0;
+        }
+    }
+    clip_u<T, M>(lim, ur, u);
+}
+
+}  // namespace hjbx

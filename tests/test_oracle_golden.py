@@ -1,0 +1,126 @@
+"""The CPU oracle (oracle/) against golden vectors produced by the reference's own NumPy branch
+(tools/gen_golden.py).  CPU only.  f64: rtol 1e-12 pointwise; closed loops: 1e-9 over hundreds of steps
+on stabilised plants (chaotic swing-ups are compared over a bounded prefix)."""
+import numpy as np
+import pytest
+
+from conftest import ANGLE_IDX, SYSTEMS, load_golden, make_dynamics, orc_system, wrapped_diff
+from oracle import oracle as O
+from q_learning_with_hjb_amd import _abi
+
+RT = 1e-12
+
+
+def close(a, b, rtol=RT, atol=1e-12):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_affine_xdot_simulate_wrap(name):
+    g = load_golden(name)
+    s = orc_system(name)
+    f1, f2 = O.affine(s, g["X"])
+    close(f1, g["F1"], atol=1e-11)
+    close(f2, g["F2"], atol=1e-11)
+    close(O.dynamics_step(s, g["X"], g["U"]), g["XDOT"], atol=1e-10)
+    xn = O.simulate(s, g["X"], g["U"])
+    assert np.abs(wrapped_diff(xn, g["XNEXT"], ANGLE_IDX[name])).max() < 1e-11
+    close(O.wrap(s, g["X"]), g["XWRAP"])
+    # seam cases must be BIT exact: same fmod-based remainder as NumPy
+    assert np.array_equal(O.wrap(s, g["XSEAM"]), g["XSEAMWRAP"])
+
+
+@pytest.mark.parametrize("name", ["cartpole", "acrobot"])
+def test_manipulator_terms(name):
+    g = load_golden(name)
+    M, C, G, E = O.manip(orc_system(name), g["X"])
+    close(M, g["M"]); close(C, g["C"]); close(G, g["G"])
+    if name == "acrobot":
+        close(E, g["E"], rtol=1e-12, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["linear", "cartpole", "quad2d", "nearhover"])
+def test_initial_state_stream(name):
+    """get_initial_state reproduces the reference's seed-0 draws from the same uniforms."""
+    g = load_golden(name)
+    d = make_dynamics(name)
+    x0 = O.initial_state(orc_system(name), d.x0_mean, d.x0_std, g["U01SEQ"])
+    close(x0, g["X0SEQ"], rtol=1e-14, atol=1e-15)
+    # and NumPy's own global stream after the constructor's np.random.seed(0) gives those uniforms
+    make_dynamics(name)
+    u = np.random.uniform(size=g["U01SEQ"].shape)
+    assert np.array_equal(u, g["U01SEQ"])
+
+
+def test_spot_values(spot):
+    """Numbers recorded in SURVEY.md 8c straight from the reference."""
+    s = orc_system("linear")
+    sv = spot["spot"]["linear"]
+    ctrl = _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, 2, 1, sv["K"], wrap_error=False)
+    u0 = O.controller(s, ctrl, sv["x0"])
+    close(u0.ravel(), sv["u0"], rtol=1e-13)
+    close(O.simulate(s, sv["x0"], u0).ravel(), sv["x1"], rtol=1e-13)
+    c = spot["spot"]["cartpole"]
+    f1, f2 = O.affine(orc_system("cartpole"), c["x0"])
+    close(f1.ravel(), c["f1"], rtol=1e-11); close(f2.ravel(), c["f2"], rtol=1e-11)
+
+
+def _ctrl(name, g):
+    if name == "linear":
+        return _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, 2, 1, g["K"], wrap_error=False)
+    if name == "quad2d":
+        return _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, 6, 2, g["K"], xf=np.zeros(6), uf=g["uf"], wrap_error=True)
+    if name == "nearhover":
+        return _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, 10, 3, g["K"], xf=np.zeros(10), uf=g["uf"], wrap_error=True)
+    if name == "cartpole":
+        return _abi.make_controller(_abi.CTRL_CARTPOLE_ENERGY, 4, 1, g["K"], xf=[0, np.pi, 0, 0], Kes=g["Kes"], eps_energy=1, eps_state=1)
+    if name == "acrobot":
+        return _abi.make_controller(_abi.CTRL_ACROBOT_ENERGY, 4, 1, g["K"], xf=[np.pi, 0, 0, 0], P=g["P"], Kes=g["Kes"], eps_region=1000)
+
+
+TRAJ = {"linear": "traj_linear_lqr", "cartpole": "traj_cartpole_es", "acrobot": "traj_acrobot_es", "quad2d": "traj_quad2d_hover",
+        "nearhover": "traj_nearhover_hover"}
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_closed_loop_trajectories(name):
+    """Config 1 (double integrator + LQR, T = 5 s) and the other model-based closed loops of the reference."""
+    g = load_golden(TRAJ[name])
+    s = orc_system(name)
+    T = g["US"].shape[0]
+    out = O.rollout_feedback(s, _ctrl(name, g), g["XS"][0], T)
+    # the energy-shaping swing-ups are sensitive (bang-bang clipping); compare a prefix tightly, the rest loosely
+    d = np.abs(wrapped_diff(out["traj"][:, 0], g["XS"], ANGLE_IDX[name]))
+    du = np.abs(out["u"][:, 0] - g["US"].reshape(T, -1))
+    if name in ("cartpole", "acrobot"):
+        assert d[:150].max() < 1e-8 and du[:150].max() < 1e-7
+        assert d.max() < 1e-4
+    else:
+        assert d.max() < 1e-9 and du.max() < 1e-9
+    assert out["done_step"][0] == T
+
+
+@pytest.mark.parametrize("name", ["cartpole", "acrobot", "quad2d", "nearhover"])
+def test_controller_pointwise(name):
+    g = load_golden("ctrl_" + {"cartpole": "cartpole_es", "acrobot": "acrobot_es", "quad2d": "quad2d_hover", "nearhover": "nearhover_hover"}[name])
+    tg = load_golden(TRAJ[name])
+    u = O.controller(orc_system(name), _ctrl(name, tg), g["X"])
+    close(u, g["U"].reshape(u.shape), rtol=1e-10, atol=1e-9)
+
+
+def test_cartpole_swingup_multi():
+    g = load_golden("traj_cartpole_es_multi")
+    tg = load_golden("traj_cartpole_es")
+    out = O.rollout_feedback(orc_system("cartpole"), _ctrl("cartpole", tg), g["X0"], 400)
+    d = np.abs(wrapped_diff(out["traj"].transpose(1, 0, 2), g["XS"], [1]))
+    assert d[:, :100].max() < 1e-8
+
+
+def test_care_schur_restatement():
+    """utils.solve_continuous_are (ordered Schur) reproduces the reference's P; A=B=Q=R=I2 gives 2.41421356 I."""
+    from q_learning_with_hjb_amd.utils.utils import solve_continuous_are
+    g = load_golden("care")
+    for tag in ("linear", "cartpole", "acrobot", "quad2d", "nearhover", "eye2"):
+        P = solve_continuous_are(g[tag + "_A"], g[tag + "_B"], g[tag + "_Q"], g[tag + "_R"])
+        np.testing.assert_allclose(P, g[tag + "_P"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(solve_continuous_are(np.eye(2), np.eye(2), np.eye(2), np.eye(2)), 2.41421356 * np.eye(2), atol=1e-7)
