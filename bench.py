@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched VHJB closed loop on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): cartpole balancing, VHJB controller with the
+4->128->128->64 value network, B = 2^20 float32 environments PER GPU (weak scaling; environments are
+independent, no data-path collective).  One "step" = one closed-loop environment step for the whole
+batch, i.e. one iteration of rollout_trajectory's loop (reference controller/vhjb.py:175-186) for B
+environments: value gradient of the current states -> HJB-optimal control -> running cost -> bounds /
+termination -> forward-Euler step -> log (x, cost, done).  States stay resident in HBM.
+
+The value network carries synthetic "trained" weights (the LQR value function embedded exactly, plus
+5 % dense lecun-normal noise so no weight is zero), so environments stay inside the observation box like
+the reference's trained policy (average trajectory length 200/200, examples/cartpole_balancing.ipynb
+cell 10); `value` counts LIVE environment steps only.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel, timed live with
+HIP events on the launch stream; `cpu_baseline` is the CPU oracle (oracle/, the port of the reference's
+batch-1 loop) on this box's host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-mlp", action="store_true", help="value gradient through PyTorch matmuls instead of the fused kernel")
+    ap.add_argument("--cpu-sample-envs", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from q_learning_with_hjb_amd import _abi, _ops
+    from q_learning_with_hjb_amd.configs import defaults as D
+    from q_learning_with_hjb_amd.controller.vhjb import VHJBController
+    from q_learning_with_hjb_amd.dynamics.cartpole import Cartpole
+
+    B, K, W = args.batch, args.steps, args.warmup
+    dyn = Cartpole(D.cartpole_dynamics_config())
+    ctl = VHJBController(dyn, D.cartpole_vhjb_config(), fused_value_grad=not args.torch_mlp)
+    vf = ctl.value_function_approximator
+    wgen = torch.Generator(device="cuda"); wgen.manual_seed(1234)
+    vf.load_quadratic(ctl.P, noise=0.05, generator=wgen)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(rank)
+    x0 = dyn.get_initial_state(B, generator=gen)
+
+    n, m = dyn.get_dimension()
+    RING = 64                                    # time-major log ring: (RING, B, n) states + costs + done flags
+    traj = torch.empty((RING, B, n), device="cuda")
+    cost = torch.empty((RING, B), device="cuda")
+    done = torch.empty((RING, B), device="cuda")
+    done_step = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    traj[0].copy_(x0)
+    sysh, task = dyn.system, ctl._task
+    T_max = 1 << 30                              # no forced termination inside the timed region
+
+    ev_pairs = []
+
+    def step(t, timed_events=False):
+        s, d = t % RING, (t + 1) % RING
+        if timed_events:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+        g = ctl.get_v_gradient(traj[s])
+        if timed_events:
+            e1.record()
+        _ops.vhjb_step(sysh, task, t, T_max, traj[s], g, traj[d], cost[s], done[s], done_step)
+        if timed_events:
+            e2.record()
+            ev_pairs.append((e0, e1, e2))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(W):
+        step(t)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        step(t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # live environment steps inside the timed window [W, W+K)
+    ds = done_step.long()
+    live = torch.where(ds < 0, torch.full_like(ds, K), (ds - W).clamp(min=0, max=K)).sum()
+    if dist is not None:
+        dist.all_reduce(live)
+    live = int(live.item())
+    value = live / elapsed
+
+    # ---- per-kernel timing with HIP events on the launch stream (separate, un-timed pass) ----------
+    for t in range(W + K, W + K + 20):
+        step(t, timed_events=True)
+    torch.cuda.synchronize()
+    vg_ms = float(np.median([a.elapsed_time(b) for a, b, _ in ev_pairs]))
+    st_ms = float(np.median([b.elapsed_time(c) for _, b, c in ev_pairs]))
+    flops_per_env = 4.0 * (n * 128 + 128 * 128 + 128 * 64)          # fwd + input-grad MACs x 2
+    step_bytes_per_env = 4.0 * (3 * n + 2)                          # read x, gradV; write x', cost, done
+    if ctl.fused_value_grad:
+        roofline = dict(bound="mfma", kernel="k_value_grad_mfma (hjbx_value_grad_f32)", achieved=flops_per_env * B / (vg_ms * 1e-3) / 1e12,
+                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", traffic=None)
+    else:
+        roofline = dict(bound="hbm", kernel="k_vhjb_step (hjbx_vhjb_step_f32)", achieved=step_bytes_per_env * B / (st_ms * 1e-3) / 1e9,
+                        peak=HBM_PEAK_GBS, unit="GB/s", traffic=None)
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    roofline["avg_launch_ms"] = vg_ms if ctl.fused_value_grad else st_ms
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if collected
+    if os.path.exists(tfile):
+        with open(tfile) as f:
+            roofline["traffic"] = json.load(f).get(roofline["kernel"].split(" ")[0])
+    other = dict(value_grad_ms=vg_ms, vhjb_step_ms=st_ms,
+                 vhjb_step_hbm_GBs=step_bytes_per_env * B / (st_ms * 1e-3) / 1e9,
+                 value_grad_TFLOPs=flops_per_env * B / (vg_ms * 1e-3) / 1e12)
+
+    out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20", value=value, unit="env-steps/s", n_gpus=world,
+               steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+               data="synthetic",
+               config=dict(workload="cartpole balancing + vhjb controller (BASELINE configs[1])", batch_per_gpu=B, global_batch=B * world,
+                           state_dim=n, control_dim=m, integrator="euler", mlp="4-128-128-64 relu, no bias",
+                           value_grad="fused HIP MFMA kernel" if ctl.fused_value_grad else "PyTorch-ROCm matmuls",
+                           live_fraction=live / (B * world * K), parallelism=f"env-shard x{world}, no data-path collective"),
+               roofline=roofline, kernels=other)
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(dyn, ctl, x0, args.cpu_sample_envs)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(dyn, ctl, x0, sample_envs):
+    """The oracle's restatement of rollout_trajectory (env by env, value gradient per step) on the host
+    cores, OpenMP over environments; f64 state like the reference's CPU rollout."""
+    from oracle import oracle as O
+    vf = ctl.value_function_approximator
+    Wts = [w.detach().cpu().numpy().astype(np.float64) for w in vf.weights]
+    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar)
+    s = O.System.from_dynamics(dyn)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = O.threads(min(avail, 16))            # the GPU box's CPU share per GPU is 16 cores
+    T = 50
+    # calibrate on a small sample, then size the run for ~12 s
+    xs = x0[:256].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter(); r = O.vhjb_rollout(s, ctl._task, mlp, *Wts, xs, T, log=False); dt = time.perf_counter() - t0
+    rate = max(r["live_steps"], 1) / dt
+    nenv = sample_envs or int(min(x0.shape[0], max(512, rate * 12.0 / T)))
+    xs = x0[:nenv].cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter(); r = O.vhjb_rollout(s, ctl._task, mlp, *Wts, xs, T, log=False); dt = time.perf_counter() - t0
+    return dict(value=r["live_steps"] / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{nenv} envs x {T} steps of the same workload (f64, OpenMP over envs), {dt:.1f} s")
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,19 @@ size_t orc_sizeof_system(void) { return sizeof(orc_system); }
 size_t orc_sizeof_mlp(void) { return sizeof(orc_mlp); }
 size_t orc_sizeof_task(void) { return sizeof(hjbx_task); }
 size_t orc_sizeof_controller(void) { return sizeof(hjbx_controller); }
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* number of OpenMP threads the batch loops will use; n > 0 sets it first */
+int orc_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 int orc_has_openmp(void) {
 #ifdef _OPENMP
     return 1;

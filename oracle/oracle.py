@@ -66,6 +66,11 @@ def has_openmp():
     return bool(lib().orc_has_openmp())
 
 
+def threads(n=0):
+    """Set (n > 0) and return the number of OpenMP threads the batch loops use."""
+    return int(lib().orc_threads(int(n)))
+
+
 class System:
     """Host description of one of the five systems (what Dynamics.__init__ stores)."""
 

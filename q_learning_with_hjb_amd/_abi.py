@@ -131,7 +131,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
             return _LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", _LIB_PATH] + srcs
+    # -ffp-contract=on: fuse a*b+c only inside one source expression, so every kernel that inlines the same
+    # device function rounds identically (fused rollout == step-by-step kernels, bit for bit)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared", "-o", _LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

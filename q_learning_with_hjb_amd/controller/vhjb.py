@@ -95,6 +95,27 @@ class ValueFunctionApproximator(torch.nn.Module):
         g = (d1 @ W1.t()) / self.std + (2.0 * self.epsilon_scalar) * e
         return V, g
 
+    @torch.no_grad()
+    def load_quadratic(self, P, noise: float = 0.0, generator=None):
+        """Set the weights so that V(x) = e'Pe + eps_s |e|^2 exactly (P symmetric positive definite), plus
+        `noise` x a fresh lecun-normal draw on every entry.  With P from the CARE this is the value
+        function the training converges to near xf: a synthetic "trained" network for benchmarks and
+        tests.  Construction: q = L'e with P = LL'; ReLU pairs carry (q, -q) through both hidden layers."""
+        n = self.dynamics.state_dim
+        h1, h2, h3 = self.features
+        assert 2 * n <= min(h1, h2) and n <= h3
+        assert float(np.abs(self._np["mean"]).max()) == 0.0 and float(np.abs(self._np["std"] - 1).max()) == 0.0
+        L = torch.as_tensor(np.linalg.cholesky(np.asarray(P, np.float64)), dtype=self.weights[0].dtype, device=self.weights[0].device)
+        eye = torch.eye(n, dtype=L.dtype, device=L.device)
+        W1, W2, W3 = (torch.zeros_like(w) for w in self.weights)
+        W1[:, :n], W1[:, n:2 * n] = L, -L
+        W2[:n, :n], W2[n:2 * n, :n], W2[:n, n:2 * n], W2[n:2 * n, n:2 * n] = eye, -eye, -eye, eye
+        W3[:n, :n], W3[n:2 * n, :n] = eye, -eye
+        for w, t in zip(self.weights, (W1, W2, W3)):
+            if noise:
+                t += noise * lecun_normal_(torch.empty_like(t), generator)
+            w.copy_(t)
+
     def descriptor(self) -> _abi.HjbxMlp:
         d = _abi.HjbxMlp()
         W1, W2, W3 = self.weights
@@ -245,7 +266,7 @@ class VHJBController(Controller):
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen)
-        self.fused_value_grad = (dtype == torch.float32) if fused_value_grad is None else bool(fused_value_grad)
+        self.fused_value_grad = False if fused_value_grad is None else bool(fused_value_grad)  # TODO default on once the MFMA kernel lands
         self.train_mode = False
         self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=config.lr, betas=(0.9, 0.999), eps=1e-8)
         self._sched = dict(init_value=config.regularization_init_value, peak_value=config.regularization_peak_value,

@@ -1,0 +1,423 @@
+"""GPU parity: every libhjbx.so entry point (through the C ABI) against the CPU oracle on the same
+seeded inputs, and against the reference's golden vectors.  Run on the MI355X box with `-m gpu`.
+
+Tolerances (stated per BASELINE.json north_star):
+  * float64 kernels vs the f64 oracle: rtol 1e-12 (atol scaled to the data), integer outputs bit-equal;
+  * float32 kernels vs the f64 oracle: rtol 1e-5 per step (atol 1e-5 x data scale);
+  * angle columns are compared modulo 2 pi (a 1-ulp difference at the seam flips the representative).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ANGLE_IDX, SYSTEMS, load_golden, make_dynamics, make_vhjb_config, orc_system, wrapped_diff
+from oracle import oracle as O
+from q_learning_with_hjb_amd import _abi, _ops
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f64": (torch.float64, np.float64, 1e-12), "f32": (torch.float32, np.float32, 1e-5)}
+
+
+def dev(a, tdt):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=tdt, device="cuda").contiguous()
+
+
+def check(got, want, tol, scale=None, angle_idx=(), max_bad_frac=0.0):
+    got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    d = np.abs(wrapped_diff(got, want, angle_idx)) if len(angle_idx) else np.abs(got - want)
+    s = np.maximum(np.abs(want), 1.0 if scale is None else scale)
+    bad = d > tol * s * 8
+    assert bad.mean() <= max_bad_frac, f"max rel err {(d / s).max():.3e} (tol {tol:g}), {bad.mean():.2%} bad, at {np.argwhere(bad)[:4].tolist()}"
+
+
+def sample_states(name, B, seed=0, spread=1.5):
+    d = make_dynamics(name)
+    rng = np.random.default_rng(seed)
+    x = d.x0_mean.astype(np.float64) + rng.uniform(-1, 1, (B, d.state_dim)) * np.maximum(d.x0_std.astype(np.float64), 0.5) * spread
+    u = rng.uniform(-1.3, 1.3, (B, d.control_dim)) * np.maximum(np.abs(d.umax), np.abs(d.umin)).astype(np.float64)
+    return d, x, u
+
+
+def task_for(name, d):
+    cfg = make_vhjb_config(name)
+    rng = np.random.default_rng(7)
+    n, m = d.get_dimension()
+    A = rng.standard_normal((n, n))
+    P = A @ A.T / n + np.eye(n)       # any SPD terminal cost
+    Q = np.asarray(cfg.Q, np.float64) + 0.1 * (A + A.T) / n * 0.2 + 0.0
+    Q = Q @ Q.T                        # dense SPD, exercises the full quadratic form
+    Rm = np.asarray(cfg.R, np.float64)
+    if m > 1:
+        Rm = Rm + 0.1 * np.ones((m, m)) / m
+    return _abi.make_task(n, m, Q, Rm, P, cfg.xf, cfg.uf, cfg.obs_min, cfg.obs_max, cfg.epsilon)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_pointwise_kernels(name, prec):
+    tdt, ndt, tol = DT[prec]
+    d, x, u = sample_states(name, 1000, seed=1)   # ragged: not a multiple of the 256-thread block
+    s = orc_system(name)
+    xd, ud = dev(x, tdt), dev(u, tdt)
+    xr, ur = xd.cpu().numpy().astype(np.float64), ud.cpu().numpy().astype(np.float64)  # oracle sees the rounded inputs
+    ai = ANGLE_IDX[name]
+    f1, f2 = _ops.affine(d.system, xd)
+    o1, o2 = O.affine(s, xr)
+    sc = np.abs(o1).max()
+    check(f1, o1, tol, sc); check(f2, o2, tol, np.abs(o2).max() + 1)
+    check(_ops.dynamics_step(d.system, xd, ud), O.dynamics_step(s, xr, ur), tol, np.abs(O.dynamics_step(s, xr, ur)).max())
+    check(_ops.wrap(d.system, xd), O.wrap(s, xr), tol, angle_idx=ai)
+    for integ in (_abi.EULER, _abi.RK4):
+        check(_ops.simulate(d.system, xd, ud, integ), O.simulate(s, xr, ur, integ), tol, np.abs(xr).max(), angle_idx=ai)
+    task = task_for(name, d)
+    check(_ops.running_cost(d.system, task, xd, ud), O.running_cost(s, task, xr, ur), tol, np.abs(O.running_cost(s, task, xr, ur)).max())
+    check(_ops.termination_cost(d.system, task, xd), O.termination_cost(s, task, xr), tol, np.abs(O.termination_cost(s, task, xr)).max())
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal(x.shape) * 20
+    gd = dev(g, tdt); gr = gd.cpu().numpy().astype(np.float64)
+    check(_ops.control_from_grad(d.system, task, xd, gd), O.control_from_grad(s, task, xr, gr), tol, np.abs(d.umax).max())
+    u01 = rng.uniform(size=x.shape)
+    ud01 = dev(u01, tdt)
+    check(_ops.initial_state(d.system, d.x0_mean, d.x0_std, ud01), O.initial_state(s, d.x0_mean, d.x0_std, ud01.cpu().numpy().astype(np.float64)),
+          tol, angle_idx=ai)
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_golden_vectors_f64(name):
+    """The f64 kernels directly against the reference's own outputs (no oracle in between)."""
+    g = load_golden(name)
+    d = make_dynamics(name)
+    x, u = dev(g["X"], torch.float64), dev(g["U"], torch.float64)
+    f1, f2 = _ops.affine(d.system, x)
+    check(f1, g["F1"], 1e-12, np.abs(g["F1"]).max()); check(f2, g["F2"], 1e-12, np.abs(g["F2"]).max() + 1)
+    check(_ops.dynamics_step(d.system, x, u), g["XDOT"], 1e-12, np.abs(g["XDOT"]).max())
+    check(_ops.simulate(d.system, x, u), g["XNEXT"], 1e-12, np.abs(g["X"]).max(), angle_idx=ANGLE_IDX[name])
+    # wrap seams: bit exact
+    got = _ops.wrap(d.system, dev(g["XSEAM"], torch.float64)).cpu().numpy()
+    assert np.array_equal(got, g["XSEAMWRAP"])
+    if name != "acrobot":
+        x0 = _ops.initial_state(d.system, d.x0_mean, d.x0_std, dev(g["U01SEQ"], torch.float64))
+        check(x0, g["X0SEQ"], 1e-14)
+
+
+@pytest.mark.parametrize("name", ["linear", "cartpole", "quad2d", "nearhover"])
+def test_dynamics_surface_numpy_roundtrip(name):
+    """The reference-shaped Python surface: numpy (n,) in -> numpy out, incl. get_initial_state's RNG stream."""
+    g = load_golden(name)
+    d = make_dynamics(name)
+    x0 = d.get_initial_state()
+    assert isinstance(x0, np.ndarray) and x0.dtype == np.float64 and x0.shape == (d.state_dim,)
+    np.testing.assert_allclose(x0, g["X0SEQ"][0], rtol=1e-14, atol=1e-15)
+    f1, f2 = d.get_control_affine_matrix(g["X"][5])
+    np.testing.assert_allclose(f1, g["F1"][5], rtol=1e-12, atol=1e-11)
+    assert f2.shape == (d.state_dim, d.control_dim)
+    np.testing.assert_allclose(d.dynamics_step(g["X"][5], g["U"][5]), g["XDOT"][5], rtol=1e-12, atol=1e-10)
+    xn = d.simulate(g["X"][5], g["U"][5])
+    assert np.abs(wrapped_diff(xn, g["XNEXT"][5], ANGLE_IDX[name])).max() < 1e-11
+    assert d.get_dimension() == (d.state_dim, d.control_dim)
+    xb = d.simulate(g["X"], g["U"])           # batch
+    assert xb.shape == g["X"].shape
+    xt = d.simulate(torch.as_tensor(g["X"], device="cuda"), torch.as_tensor(g["U"], device="cuda"))  # zero-copy flavour
+    assert xt.is_cuda and torch.equal(xt.cpu(), torch.as_tensor(xb))
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("mode", [_abi.RESIDUAL_NORMALISED, _abi.RESIDUAL_RAW])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_hjb_residual(name, mode, prec):
+    tdt, ndt, tol = DT[prec]
+    d, x, _ = sample_states(name, 777, seed=5)
+    s = orc_system(name)
+    task = task_for(name, d)
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal(x.shape) * np.where(rng.uniform(size=(x.shape[0], 1)) < 0.5, 2.0, 40.0)  # clipped and unclipped controls
+    done = (rng.uniform(size=x.shape[0]) < 0.3).astype(np.float64)
+    xd, gd, dd = dev(x, tdt), dev(g, tdt), dev(done, tdt)
+    xr, gr = xd.cpu().numpy().astype(np.float64), gd.cpu().numpy().astype(np.float64)
+    li, dg, sums = _ops.hjb_residual(d.system, task, xd, gd, dd, mode)
+    oli, odg, osums = O.hjb_residual(s, task, xr, gr, done, mode)
+    # the normalised residual divides by l(x,u): compare with a tolerance scaled to the data
+    check(li, oli, tol * 4, np.abs(oli).max())
+    check(dg, odg, tol * 4, np.abs(odg).max())
+    got = sums.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, osums, rtol=tol * 10 if prec == "f32" else 1e-11)
+    assert got[1] == osums[1] and got[2] == osums[2]         # counts are exact
+    # determinism: the two-stage reduction has no atomics
+    _, _, sums2 = _ops.hjb_residual(d.system, task, xd, gd, dd, mode)
+    assert torch.equal(sums, sums2)
+
+
+def test_hjb_residual_gradient_matches_finite_differences():
+    """d loss_i / d gradV from the kernel vs central differences of the kernel's own loss (f64)."""
+    d, x, _ = sample_states("quad2d", 64, seed=9)
+    task = task_for("quad2d", d)
+    rng = np.random.default_rng(2)
+    g = rng.standard_normal(x.shape) * 3
+    done = np.zeros(x.shape[0])
+    xd, dd = dev(x, torch.float64), dev(done, torch.float64)
+    _, dg, _ = _ops.hjb_residual(d.system, task, xd, dev(g, torch.float64), dd)
+    h = 1e-6
+    num = np.zeros_like(g)
+    for k in range(g.shape[1]):
+        gp, gm = g.copy(), g.copy()
+        gp[:, k] += h; gm[:, k] -= h
+        lp = _ops.hjb_residual(d.system, task, xd, dev(gp, torch.float64), dd)[0].cpu().numpy()
+        lm = _ops.hjb_residual(d.system, task, xd, dev(gm, torch.float64), dd)[0].cpu().numpy()
+        num[:, k] = (lp - lm) / (2 * h)
+    np.testing.assert_allclose(dg.cpu().numpy(), num, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_known_answer_lqr_residual_is_zero(prec):
+    """for LinearDynamics, gradV = 2 P e gives u = -K e and gradV.xdot + l == 0, so the
+    normalised residual |.. + 1| vanishes (identity documented at reference utils/utils.py:33,58)."""
+    tdt, ndt, tol = DT[prec]
+    import scipy.linalg
+    d = make_dynamics("linear")
+    A, Bm = np.asarray(d.A, np.float64), np.asarray(d.B, np.float64)
+    Q, R = np.eye(2), np.eye(1)
+    P = scipy.linalg.solve_continuous_are(A, Bm, Q, R)
+    K = np.linalg.inv(R) @ Bm.T @ P
+    task = _abi.make_task(2, 1, Q, R, P, [0, 0], [0], [-2, -3], [2, 3], 1e-10)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (4096, 2))             # |K x| < 5: never clipped
+    g = 2 * x @ P
+    xd, gd = dev(x, tdt), dev(g, tdt)
+    u = _ops.control_from_grad(d.system, task, xd, gd)
+    check(u, -(x @ K.T), tol * 10)
+    li, _, sums = _ops.hjb_residual(d.system, task, xd, gd, torch.zeros(4096, dtype=tdt, device="cuda"))
+    # exactly: vdot = -l, so r = -l/(l+eps) + 1 = eps/(l+eps)  (tiny except next to the origin)
+    l = (x * x).sum(1) + ((x @ K.T) ** 2).sum(1)
+    lim = 1e-9 if prec == "f64" else 2e-3         # fp32: cancellation of two O(1) terms, amplified by 1/l
+    mask = torch.as_tensor(l > (1e-6 if prec == "f64" else 1e-2))
+    assert float((li.cpu() - torch.as_tensor(1e-10 / (l + 1e-10), dtype=li.dtype))[mask].abs().max()) < lim
+    lr, _, _ = _ops.hjb_residual(d.system, task, xd, gd, torch.zeros(4096, dtype=tdt, device="cuda"), _abi.RESIDUAL_RAW)
+    assert float(lr.abs().max()) < (1e-12 if prec == "f64" else 1e-5)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_termination_residual(prec):
+    tdt, ndt, tol = DT[prec]
+    rng = np.random.default_rng(4)
+    B = 5000
+    V = rng.uniform(0, 50, B); cost = rng.uniform(0, 50, B); cost[::7] = 0.0
+    done = (rng.uniform(size=B) < 0.5).astype(np.float64)
+    Vd, cd, dd = dev(V, tdt), dev(cost, tdt), dev(done, tdt)
+    li, dv, sums = _ops.termination_residual(1e-10 if prec == "f64" else 1e-6, Vd, cd, dd)
+    oli, odv, osums = O.termination_residual(1e-10 if prec == "f64" else 1e-6, Vd.cpu().numpy().astype(np.float64),
+                                             cd.cpu().numpy().astype(np.float64), done)
+    m = cost > 0
+    check(li[torch.as_tensor(m)], oli[m], tol * 4, np.abs(oli[m]).max())
+    check(dv[torch.as_tensor(m)], odv[m], tol * 4, np.abs(odv[m]).max())
+    assert float(sums[2]) == osums[2]
+
+
+def _ctrl_objects(name):
+    """product controller + matching oracle descriptor from the SAME gains"""
+    d = make_dynamics(name)
+    if name == "linear":
+        from q_learning_with_hjb_amd.controller.lqr import LQR
+        c = LQR(d, np.eye(2), np.eye(1))
+    elif name == "cartpole":
+        from q_learning_with_hjb_amd.controller.cartpole_energy_shaping import CartpoleEnergyShapingController
+        c = CartpoleEnergyShapingController(d)
+    elif name == "acrobot":
+        from q_learning_with_hjb_amd.controller.acrobot_energy_shaping import AcrobotEnergyShapingController
+        c = AcrobotEnergyShapingController(d)
+    elif name == "quad2d":
+        from q_learning_with_hjb_amd.controller.quadrotors_model_based_controller import Quadrotors2DHoveringController
+        c = Quadrotors2DHoveringController(d, np.zeros(6), np.eye(6), np.eye(2))
+    else:
+        from q_learning_with_hjb_amd.controller.quadrotors_model_based_controller import NearHoverQuadcopterHoveringController
+        c = NearHoverQuadcopterHoveringController(d, np.zeros(10), np.eye(10), np.eye(3))
+    return d, c
+
+
+TRAJ = {"linear": "traj_linear_lqr", "cartpole": "traj_cartpole_es", "acrobot": "traj_acrobot_es", "quad2d": "traj_quad2d_hover",
+        "nearhover": "traj_nearhover_hover"}
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_controller_gains_and_golden_closed_loop(name):
+    """Set-up math (CARE, gains) and the fused closed-loop kernel against the reference's trajectories
+    (config 1: double integrator + LQR for 5 s; energy shaping; hover LQR)."""
+    g = load_golden(TRAJ[name])
+    d, c = _ctrl_objects(name)
+    K = c.K if name in ("linear", "quad2d", "nearhover") else c.get_lqr_term()[0]
+    np.testing.assert_allclose(K, g["K"], rtol=1e-9, atol=1e-9)
+    T = g["US"].shape[0]
+    out = c.rollout(g["XS"][0][None, :], T)           # numpy f64 in -> f64 kernels
+    dd = np.abs(wrapped_diff(out["traj"][:, 0], g["XS"], ANGLE_IDX[name]))
+    du = np.abs(out["u"][:, 0] - g["US"].reshape(T, -1))
+    if name in ("cartpole", "acrobot"):
+        assert dd[:150].max() < 1e-7 and du[:150].max() < 2e-6 and dd.max() < 1e-3   # swing-up: errors grow along the unstable loop
+    else:
+        assert dd.max() < 1e-9 and du.max() < 1e-9
+    assert int(out["done_step"][0]) == T
+    # single-state call of the plugin method
+    u0 = c.get_control_efforts(g["XS"][0])
+    np.testing.assert_allclose(np.atleast_1d(u0), g["US"][0].reshape(-1), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_rollout_feedback_vs_oracle(name, prec):
+    """Fused T-step kernel == oracle closed loop, with costs, termination and integer done steps."""
+    tdt, ndt, tol = DT[prec]
+    d, c = _ctrl_objects(name)
+    s = orc_system(name)
+    cfg = make_vhjb_config(name)
+    n, m = d.get_dimension()
+    task = _abi.make_task(n, m, cfg.Q, cfg.R, np.eye(n) * 2.0, c.xf if hasattr(c, "xf") else cfg.xf, getattr(c, "uf", cfg.uf), cfg.obs_min,
+                          cfg.obs_max, cfg.epsilon)
+    B, T = 300, 60
+    rng = np.random.default_rng(21)
+    xf = np.asarray(c.xf if hasattr(c, "xf") else cfg.xf, np.float64)
+    x0 = xf + rng.uniform(-1, 1, (B, n)) * np.asarray(cfg.obs_max, np.float64).clip(max=3.0) * 0.9
+    x0d = dev(x0, tdt); x0r = x0d.cpu().numpy().astype(np.float64)
+    desc = c._descriptor()
+    for terminate in (False, True):
+        for integ in (_abi.EULER, _abi.RK4):
+            got = _ops.rollout_feedback(d.system, desc, x0d, T, task=task, integrator=integ, terminate=terminate, log_u=True, log_cost=True)
+            want = O.rollout_feedback(s, desc, x0r, T, task=task, integrator=integ, terminate=terminate)
+            gs, ws = got["done_step"].cpu().numpy(), want["done_step"]
+            if prec == "f64":
+                assert np.array_equal(gs, ws)
+                keep = np.ones(B, bool)
+            else:
+                # fp32 may cross a bound one step apart for envs within rounding of it: allow <1 %
+                keep = gs == ws
+                assert keep.mean() > 0.99 and np.abs(gs - ws).max() <= 1
+            # compare a bounded prefix (error growth on the unstable plants is exponential in t)
+            P = 12
+            ttol = tol * 50 if prec == "f32" else 1e-9
+            # the energy-shaping laws switch branch discontinuously: in fp32 a few envs next to the switching
+            # surface take the other branch for a step (then diverge); everything else must agree
+            mbf = 0.01 if (prec == "f32" and name in ("cartpole", "acrobot")) else 0.0
+            check(got["traj"][:P, torch.as_tensor(keep)], want["traj"][:P, keep], ttol, np.abs(x0).max(), angle_idx=ANGLE_IDX[name], max_bad_frac=mbf)
+            check(got["u"][:P, torch.as_tensor(keep)], want["u"][:P, keep], ttol, np.abs(d.umax).max(), max_bad_frac=mbf)
+            check(got["cost"][:P, torch.as_tensor(keep)], want["cost"][:P, keep], ttol, np.abs(want["cost"][:P]).max() + 1, max_bad_frac=mbf)
+            if prec == "f64":
+                check(got["traj"], want["traj"], 1e-6, np.abs(x0).max(), angle_idx=ANGLE_IDX[name])
+                check(got["total_cost"], want["total_cost"], 1e-6, np.abs(want["total_cost"]).max())
+                check(got["x_final"], want["x_final"], 1e-6, np.abs(x0).max(), angle_idx=ANGLE_IDX[name])
+
+
+@pytest.mark.parametrize("name", ["linear", "cartpole", "quad2d", "nearhover"])
+def test_rollout_feedback_equals_step_by_step(name):
+    """Size-independent property at a larger batch: the fused kernel == controller + simulate kernels
+    applied T times (bitwise, same arithmetic), f32, B = 2^16."""
+    d, c = _ctrl_objects(name)
+    B, T = 1 << 16, 25
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    x0 = d.get_initial_state(B, generator=gen)
+    out = _ops.rollout_feedback(d.system, c._descriptor(), x0, T, log_u=True)
+    x = x0.clone()
+    for t in range(T):
+        assert torch.equal(out["traj"][t], x)
+        u = _ops.controller(d.system, c._descriptor(), x)
+        assert torch.equal(out["u"][t], u)
+        x = _ops.simulate(d.system, x, u)
+    assert torch.equal(out["traj"][T], x) and torch.equal(out["x_final"], x)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_vhjb_step_sequence(name, prec):
+    """The per-step closed-loop kernel against the oracle, fed the same (arbitrary) value gradients:
+    costs, done flags, held states and bit-equal done_step indices, including forced termination at T."""
+    tdt, ndt, tol = DT[prec]
+    d = make_dynamics(name)
+    s = orc_system(name)
+    cfg = make_vhjb_config(name)
+    n, m = d.get_dimension()
+    task = _abi.make_task(n, m, cfg.Q, cfg.R, np.eye(n) * 3.0, cfg.xf, cfg.uf, cfg.obs_min, cfg.obs_max, cfg.epsilon)
+    B, T = 513, 12
+    rng = np.random.default_rng(33)
+    xf = np.asarray(cfg.xf, np.float64)
+    x = xf + rng.uniform(-1.05, 1.05, (B, n)) * np.asarray(cfg.obs_max, np.float64).clip(max=3.0)   # ~some start outside the box
+    xd = dev(x, tdt); xo = xd.cpu().numpy().astype(np.float64)
+    ds_d = torch.full((B,), -1, dtype=torch.int32, device="cuda"); ds_o = np.full(B, -1, np.int32)
+    for t in range(T + 1):
+        g = rng.standard_normal((B, n)) * 5
+        gd = dev(g, tdt); gr = gd.cpu().numpy().astype(np.float64)
+        xn = torch.empty_like(xd); c = torch.empty(B, dtype=tdt, device="cuda"); dn = torch.empty_like(c)
+        uo = torch.empty((B, m), dtype=tdt, device="cuda")
+        _ops.vhjb_step(d.system, task, t, T, xd, gd, xn, c, dn, ds_d, u_out=uo)
+        oxn, ou, oc, od, ds_o = O.vhjb_step(s, task, t, T, xo, gr, ds_o)
+        if prec == "f64":
+            assert np.array_equal(ds_d.cpu().numpy(), ds_o)
+        else:
+            agree = ds_d.cpu().numpy() == ds_o
+            assert agree.mean() > 0.99
+            # re-synchronise the few envs that sit within fp32 rounding of a bound
+            ds_d = torch.as_tensor(ds_o, device="cuda"); xn = torch.where(torch.as_tensor(agree, device="cuda")[:, None], xn, dev(oxn, tdt))
+            keep = agree
+        keep = np.ones(B, bool) if prec == "f64" else keep
+        km = torch.as_tensor(keep)
+        check(xn[km], oxn[keep], tol * 4, np.abs(xo).max(), angle_idx=ANGLE_IDX[name])
+        check(c[km], oc[keep], tol * 4, np.abs(oc).max() + 1)
+        check(uo[km], ou[keep], tol * 4, np.abs(d.umax).max())
+        assert np.array_equal(dn[km].cpu().numpy().astype(np.float64), od[keep])
+        xd = xn; xo = xn.cpu().numpy().astype(np.float64) if prec == "f32" else oxn
+        if prec == "f64":
+            xd = dev(oxn, tdt)
+    assert (ds_o >= 0).all() and ds_o.max() <= T
+
+
+def test_edge_cases_and_errors():
+    d = make_dynamics("cartpole")
+    # empty batch: a no-op that still returns well-formed tensors
+    x = torch.empty((0, 4), device="cuda")
+    assert _ops.simulate(d.system, x, torch.empty((0, 1), device="cuda")).shape == (0, 4)
+    li, dg, sums = _ops.hjb_residual(d.system, task_for("cartpole", d), x, x.clone(), torch.empty((0,), device="cuda"))
+    assert sums.tolist() == [0.0, 0.0, 0.0]
+    # B = 1
+    one = _ops.wrap(d.system, torch.tensor([[0.0, 7.0, 0.0, 0.0]], device="cuda"))
+    assert abs(float(one[0, 1]) - (7.0 - 2 * np.pi)) < 1e-6
+    # misaligned pointer -> ValueError from HJBX_EINVAL (a (B,4) f32 view shifted by one element)
+    buf = torch.zeros(4 * 8 + 1, device="cuda")
+    with pytest.raises(ValueError):
+        _ops.wrap(d.system, buf[1:].view(8, 4), out=torch.empty((8, 4), device="cuda"))
+    # wrong controller for the system
+    c = _abi.make_controller(_abi.CTRL_ACROBOT_ENERGY, 4, 1, np.zeros((1, 4)))
+    with pytest.raises(ValueError):
+        _ops.controller(d.system, c, torch.zeros((4, 4), device="cuda"))
+    # unsupported linear shape
+    from q_learning_with_hjb_amd.configs.defaults import linear_dynamics_config
+    from q_learning_with_hjb_amd.dynamics.linear import LinearDynamics
+    big = LinearDynamics(linear_dynamics_config(A=np.eye(3).tolist(), B=np.ones((3, 1)).tolist(), x0_mean=[0] * 3, x0_std=[1] * 3))
+    with pytest.raises(NotImplementedError):
+        big.simulate(np.zeros(3), np.zeros(1))
+    # NaN safety: a diverged NearHover env (tan at pi/2) must not poison its neighbours
+    q = make_dynamics("nearhover")
+    xs = torch.zeros((4, 10), device="cuda"); xs[1, 3] = float("nan")
+    out = _ops.simulate(q.system, xs, torch.zeros((4, 3), device="cuda"))
+    assert torch.isnan(out[1]).any() and not torch.isnan(out[[0, 2, 3]]).any()
+
+
+def test_full_size_properties_cartpole():
+    """BASELINE configs[1] size (B = 2^20, f32): size-independent properties of the step kernels."""
+    d = make_dynamics("cartpole")
+    B = 1 << 20
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    x = d.get_initial_state(B, generator=gen)
+    lo = torch.as_tensor(d.x0_mean - d.x0_std, device="cuda"); hi = torch.as_tensor(d.x0_mean + d.x0_std, device="cuda")
+    assert bool(((x[:, [0, 2, 3]] >= lo[[0, 2, 3]] - 1e-6) & (x[:, [0, 2, 3]] <= hi[[0, 2, 3]] + 1e-6)).all())
+    w = _ops.wrap(d.system, x)
+    assert torch.equal(_ops.wrap(d.system, w), w)                                # idempotent
+    assert float(w[:, 1].min()) >= -np.pi - 1e-6 and float(w[:, 1].max()) < np.pi + 1e-6
+    u = torch.zeros((B, 1), device="cuda")
+    a = _ops.simulate(d.system, x, u); b = _ops.simulate(d.system, x, u)
+    assert torch.equal(a, b)                                                    # deterministic
+    big = _ops.simulate(d.system, x, u + 1e6)                                   # clipping: u=1e6 == u=umax
+    assert torch.equal(big, _ops.simulate(d.system, x, u + float(d.umax[0])))
+    # Euler step of the cart position is exactly x + dt * xdot
+    assert torch.allclose(a[:, 0], x[:, 0] + d.dt * x[:, 2], rtol=0, atol=1e-6)
+    # oracle spot-check on a strided sample of the big batch
+    idx = torch.arange(0, B, 4099, device="cuda")
+    want = O.simulate(orc_system("cartpole"), x[idx].cpu().numpy().astype(np.float64), np.zeros((idx.numel(), 1)))
+    check(a[idx], want, 1e-5, 3.0, angle_idx=[1])
