@@ -26,7 +26,7 @@ OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
 _SOURCES = ("hjbx_kernels.hip", "hjbx_mlp.hip")
-_HEADERS = ("hjbx_systems.hpp", os.path.join("..", "..", "include", "hjbx.h"))
+_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 
 
 class HjbxTask(C.Structure):

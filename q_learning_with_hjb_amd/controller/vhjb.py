@@ -266,7 +266,7 @@ class VHJBController(Controller):
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen)
-        self.fused_value_grad = False if fused_value_grad is None else bool(fused_value_grad)  # TODO default on once the MFMA kernel lands
+        self.fused_value_grad = (dtype == torch.float32) if fused_value_grad is None else bool(fused_value_grad)
         self.train_mode = False
         self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=config.lr, betas=(0.9, 0.999), eps=1e-8)
         self._sched = dict(init_value=config.regularization_init_value, peak_value=config.regularization_peak_value,

