@@ -421,14 +421,10 @@ class VHJBController(Controller):
         t_sum, _ = _TerminationResidualSum.apply(V, costs, dones, self.epsilon)
         g_h = torch.autograd.grad(h_sum, params, retain_graph=True, allow_unused=True)
         g_t = torch.autograd.grad(t_sum, params, allow_unused=True)
-        flat = pack_flat(g_h, g_t, params, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]))
-        if self._distributed():
-            torch.distributed.all_reduce(flat, group=self.process_group)
-        g_h, g_t, (hs, ts, n_int, n_done) = unpack_flat(flat, params)
-        hjb_loss = hs / (n_int + self.epsilon)
-        termination_loss = ts / (n_done + self.epsilon)
-        for p, a, b in zip(params, g_h, g_t):
-            p.grad = a / (n_int + self.epsilon) + regularization * (b / (n_done + self.epsilon))
+        grads, hjb_loss, termination_loss = allreduce_and_mix(g_h, g_t, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]), params,
+                                                              regularization, self.epsilon, self.process_group if self._distributed() else False)
+        for p, gr in zip(params, grads):
+            p.grad = gr
         self.optimizer.step()
         return hjb_loss + regularization * termination_loss, hjb_loss, termination_loss
 
@@ -494,6 +490,22 @@ class VHJBController(Controller):
 # ------------------------------------------------------------------------------------------------
 # flat gradient buffer for the single all-reduce (SURVEY 8e)
 # ------------------------------------------------------------------------------------------------
+def allreduce_and_mix(g_h, g_t, scalars, params, regularization, epsilon, process_group=None):
+    """The data-parallel step of params_update.  Inputs are THIS rank's gradients of the loss SUMS
+    (hjb, termination) and `scalars` = (sum hjb, sum termination, #interior, #done) of its shard.
+    One flat all-reduce (sum) over [g_h | g_t | scalars], then the division by the GLOBAL counts
+    (vhjb.py:241, 253) -- per-rank means would be wrong when shards hold different numbers of done states.
+    `process_group=False` skips the collective (single process).  -> (mixed grads, hjb_loss, termination_loss)"""
+    flat = pack_flat(g_h, g_t, params, scalars)
+    if process_group is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(flat, group=process_group)
+    g_h, g_t, (hs, ts, n_int, n_done) = unpack_flat(flat, params)
+    hjb_loss = hs / (n_int + epsilon)
+    termination_loss = ts / (n_done + epsilon)
+    grads = [a / (n_int + epsilon) + regularization * (b / (n_done + epsilon)) for a, b in zip(g_h, g_t)]
+    return grads, hjb_loss, termination_loss
+
+
 def pack_flat(g_h, g_t, params, scalars) -> torch.Tensor:
     """[grad of sum(hjb) | grad of sum(termination) | scalars...] as one contiguous buffer."""
     parts = []
