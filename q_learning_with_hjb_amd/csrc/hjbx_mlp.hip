@@ -39,6 +39,33 @@ __device__ __forceinline__ constexpr int perm(int s) { return (s & 3) + 8 * (s >
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+
+// One GEMM of the chain: acc[o] += A_o(step) x b(step) for step = 0..NSTEPS-1, o = 0..NOUT-1.
+// The A operands (one LDS dword per MFMA) are fetched DEPTH steps ahead of the MFMAs that consume
+// them, so a wave keeps the matrix pipe busy on its own instead of exposing the ds_read latency
+// before every group (the naive loop waits lgkmcnt(0) in front of each group: 51 % of peak).
+template <int NSTEPS, int NOUT, int DEPTH, typename LoadA, typename GetB>
+__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NOUT], LoadA loadA, GetB getB) {
+    float ring[DEPTH + 1][NOUT];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) ring[d][o] = (d < NSTEPS) ? loadA(d, o) : 0.f;
+#pragma unroll
+    for (int st = 0; st < NSTEPS; ++st) {
+        if (st + DEPTH < NSTEPS) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) ring[(st + DEPTH) % (DEPTH + 1)][o] = loadA(st + DEPTH, o);
+        }
+        // keep the prefetch in front of this step's MFMAs (the machine scheduler otherwise sinks the
+        // ds_read behind them and re-uses the operand registers, serialising read -> wait -> MFMA)
+        __builtin_amdgcn_sched_barrier(0);
+        const float b = getB(st);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[o] = MFMA(ring[st % (DEPTH + 1)][o], b, acc[o]);
+    }
+}
+
 template <typename S>
 __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
                                                                 const float* __restrict__ W2g, const float* __restrict__ W3g,
@@ -70,6 +97,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
     const bool w1row = i < N;
 
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+        // the weights are loop invariant: without this barrier LICM hoists hundreds of LDS reads out of the
+        // tile loop into registers and spills them to scratch
+        asm volatile("" ::: "memory");
         const int64_t env = tile * 32 + i;
         const bool valid = env < B;
         float xs[N], e[N], z[N];
@@ -110,12 +140,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a1[fb][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < N / 2; ++s) {
-            const float b = h ? z[2 * s + 1] : z[2 * s];
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) a1[fb] = MFMA(w1f[2 * s * kLD1 + 32 * fb], b, a1[fb]);
-        }
+        mfma_chain<N / 2, 4, 1>(
+            a1, [&](int st, int fb) { return w1f[2 * st * kLD1 + 32 * fb]; }, [&](int st) { return h ? z[2 * st + 1] : z[2 * st]; });
         uint32_t m1[4];
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
@@ -134,14 +160,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[fb][r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float b = a1[kb][s];
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) a2[fb] = MFMA(w2f[(32 * kb + perm(s)) * kLD2 + 32 * fb], b, a2[fb]);
-            }
+        mfma_chain<64, 4, 1>(
+            a2, [&](int st, int fb) { return w2f[(32 * (st >> 4) + perm(st & 15)) * kLD2 + 32 * fb]; },
+            [&](int st) { return a1[st >> 4][st & 15]; });
         uint32_t m2[4];
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
@@ -160,14 +181,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[ob][r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float b = a2[kb][s];
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) y[ob] = MFMA(w3f[(32 * kb + perm(s)) * kLD3 + 32 * ob], b, y[ob]);
-            }
+        mfma_chain<64, 2, 2>(
+            y, [&](int st, int ob) { return w3f[(32 * (st >> 4) + perm(st & 15)) * kLD3 + 32 * ob]; },
+            [&](int st) { return a2[st >> 4][st & 15]; });
 
         float vpart = 0.f;
 #pragma unroll
@@ -187,14 +203,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[fb][r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float b = y[kb][s];
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) d2[fb] = MFMA(w3b[32 * fb * kLD3 + 32 * kb + perm(s)], b, d2[fb]);
-            }
+        mfma_chain<32, 4, 1>(
+            d2, [&](int st, int fb) { return w3b[32 * fb * kLD3 + 32 * (st >> 4) + perm(st & 15)]; },
+            [&](int st) { return y[st >> 4][st & 15]; });
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
@@ -206,30 +217,22 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[fb][r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float b = d2[kb][s];
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) d1[fb] = MFMA(w2b[32 * fb * kLD2 + 32 * kb + perm(s)], b, d1[fb]);
-            }
+        mfma_chain<64, 4, 1>(
+            d1, [&](int st, int fb) { return w2b[32 * fb * kLD2 + 32 * (st >> 4) + perm(st & 15)]; },
+            [&](int st) { return d2[st >> 4][st & 15]; });
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[fb][r] = ((m1[fb] >> r) & 1u) ? d1[fb][r] : 0.f;
 
         // ---- backward 1: dZ' (N x 32, padded to 32 rows) = W1 (N x 128) . dH1' ------------------------------
-        f32x16 dz;
+        f32x16 dzv[1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz[r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float wv = w1b[32 * kb + perm(s)];
-                dz = MFMA(w1row ? wv : 0.f, d1[kb][s], dz);
-            }
+        for (int r = 0; r < 16; ++r) dzv[0][r] = 0.f;
+        mfma_chain<64, 1, 4>(
+            dzv, [&](int st, int) { const float wv = w1b[32 * (st >> 4) + perm(st & 15)]; return w1row ? wv : 0.f; },
+            [&](int st) { return d1[st >> 4][st & 15]; });
+        const f32x16 dz = dzv[0];
 
         // row k of dZ' sits in register (k&3) + 4(k>>3) of lane-half (k>>2)&1; gather the N rows on half 0
         float g[N];
