@@ -133,7 +133,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=on: fuse a*b+c only inside one source expression, so every kernel that inlines the same
     # device function rounds identically (fused rollout == step-by-step kernels, bit for bit)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared", "-o", _LIB_PATH] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared", "-o", _LIB_PATH] + os.environ.get("HJBX_EXTRA_FLAGS", "").split() + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

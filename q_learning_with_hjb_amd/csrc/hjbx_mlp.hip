@@ -20,6 +20,8 @@
 // Per environment: 4(128 n + 128*128 + 128*64) flop; algorithmic HBM traffic 4(2n+1) bytes -> MFMA bound.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "hjbx_internal.hpp"
 #include "hjbx_systems.hpp"
 
@@ -29,7 +31,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static constexpr int kH1 = 128, kH2 = 128, kH3 = 64;
 static constexpr int kLD1 = 129, kLD2 = 129, kLD3 = 65;  // odd LDS row strides (floats)
-static constexpr int kWaves = 8;                          // 512 threads: 2 waves per SIMD
+#ifndef HJBX_MLP_WAVES
+#define HJBX_MLP_WAVES 8
+#endif
+static constexpr int kWaves = HJBX_MLP_WAVES;             // 8 waves = 512 threads: 2 waves per SIMD
 static constexpr int kThreads = kWaves * 64;
 
 template <int N> struct MlpP { float mean[N], std[N], xf[N], eps_s; };
@@ -39,46 +44,117 @@ __device__ __forceinline__ constexpr int perm(int s) { return (s & 3) + 8 * (s >
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// relu as ONE instruction: fmaxf / fmed3f compile to a canonicalising v_max plus the v_max, and every instruction
+// issued between two MFMAs of this kernel costs matrix-pipe time (tools/ubench/mfma_mix.hip: ~4 cycles each).
+// max on the raw bits as a signed integer is the same function (negative floats and -0.0 have the sign bit set
+// -> 0; positive floats and +NaN pass through) and stays visible to the compiler's MFMA hazard padding, which an
+// inline-asm v_max_f32 would not.
+__device__ __forceinline__ float relu1(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 
-// One GEMM of the chain: acc[o] += A_o(step) x b(step) for step = 0..NSTEPS-1, o = 0..NOUT-1.
-// The A operands (one LDS dword per MFMA) are fetched DEPTH steps ahead of the MFMAs that consume
-// them, so a wave keeps the matrix pipe busy on its own instead of exposing the ds_read latency
-// before every group (the naive loop waits lgkmcnt(0) in front of each group: 51 % of peak).
-template <int NSTEPS, int NOUT, int DEPTH, typename LoadA, typename GetB>
-__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NOUT], LoadA loadA, GetB getB) {
-    float ring[DEPTH + 1][NOUT];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) ring[d][o] = (d < NSTEPS) ? loadA(d, o) : 0.f;
-#pragma unroll
-    for (int st = 0; st < NSTEPS; ++st) {
-        if (st + DEPTH < NSTEPS) {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) ring[(st + DEPTH) % (DEPTH + 1)][o] = loadA(st + DEPTH, o);
-        }
-        // keep the prefetch in front of this step's MFMAs (the machine scheduler otherwise sinks the
-        // ds_read behind them and re-uses the operand registers, serialising read -> wait -> MFMA)
-        __builtin_amdgcn_sched_barrier(0);
-        const float b = getB(st);
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) acc[o] = MFMA(ring[st % (DEPTH + 1)][o], b, acc[o]);
+
+// ---- software-pipelined MFMA chain ------------------------------------------------------------------------
+// One GEMM of the chain: acc[o] += A_o(step) x b(step), step = 0..NSTEPS-1, o = 0..NOUT-1, where every A operand
+// is one LDS dword per lane.  hipcc sinks compiler-visible ds_reads down to their MFMAs and re-uses two operand
+// registers (read -> lgkmcnt(0) -> 2 MFMAs: 77 % pipe utilisation for a lone wave), whatever the source order or
+// sched_barrier placement.  So the reads are issued from inline asm DEPTH steps ahead and retired with counted
+// s_waitcnt lgkmcnt(N) statements that name their destination registers (guide 5.7, form ii): LDS returns in
+// order, so "at most N newer operations outstanding" means this step's operands have landed.  Any LDS / SMEM
+// operation the compiler adds in between only makes the count conservative.
+template <int BYTE_OFF> __device__ __forceinline__ float lds_read_b32(uint32_t addr) {
+    static_assert(BYTE_OFF >= 0 && BYTE_OFF < 65536, "ds_read_b32 offset field is 16 bits");
+    float v;
+#ifdef HJBX_DIAG_NOLDS  // diagnostic: matrix-pipe ceiling of this kernel structure without its LDS traffic (wrong results)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(addr));
+#else
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(BYTE_OFF));
+#endif
+    return v;
+}
+template <int CNT> __device__ __forceinline__ void lds_wait(float& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(CNT));
+}
+template <int CNT> __device__ __forceinline__ void lds_wait(float& a, float& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(CNT));
+}
+template <int CNT> __device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT));
+}
+
+template <typename Off, int ST, int NOUT, int O = 0> __device__ __forceinline__ void chain_issue(float (&slot)[NOUT], uint32_t base) {
+    if constexpr (O < NOUT) {
+        slot[O] = lds_read_b32<Off::at(ST, O)>(base);
+        chain_issue<Off, ST, NOUT, O + 1>(slot, base);
     }
 }
 
+template <typename Off, int NSTEPS, int NOUT, int DEPTH, int ST = 0, typename GetB>
+__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NOUT], float (&ring)[DEPTH + 1][NOUT], uint32_t base, GetB getB) {
+    static_assert(NOUT == 1 || NOUT == 2 || NOUT == 4, "");
+    static_assert(NOUT * DEPTH <= 15, "lgkmcnt is a 4-bit field");
+    if constexpr (ST == 0) {  // prologue: the first DEPTH steps' operands
+        if constexpr (0 < DEPTH && 0 < NSTEPS) chain_issue<Off, 0, NOUT>(ring[0], base);
+        if constexpr (1 < DEPTH && 1 < NSTEPS) chain_issue<Off, 1, NOUT>(ring[1], base);
+        if constexpr (2 < DEPTH && 2 < NSTEPS) chain_issue<Off, 2, NOUT>(ring[2], base);
+        static_assert(DEPTH <= 3, "");
+    }
+    if constexpr (ST < NSTEPS) {
+        if constexpr (ST + DEPTH < NSTEPS) chain_issue<Off, ST + DEPTH, NOUT>(ring[(ST + DEPTH) % (DEPTH + 1)], base);
+        constexpr int ahead = (NSTEPS - 1 - ST < DEPTH ? NSTEPS - 1 - ST : DEPTH) * NOUT;  // reads issued after this step's
+        float(&cur)[NOUT] = ring[ST % (DEPTH + 1)];
+        if constexpr (NOUT == 1) lds_wait<ahead>(cur[0]);
+        if constexpr (NOUT == 2) lds_wait<ahead>(cur[0], cur[1]);
+        if constexpr (NOUT == 4) lds_wait<ahead>(cur[0], cur[1], cur[2], cur[3]);
+        const float b = getB(ST);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[o] = MFMA(cur[o], b, acc[o]);
+        __builtin_amdgcn_sched_barrier(0);  // keep this step's MFMAs in front of the next step's reads and wait
+        mfma_chain<Off, NSTEPS, NOUT, DEPTH, ST + 1>(acc, ring, base, getB);
+    }
+}
+
+// byte offsets (from the lane-dependent base) of the A operand of (step, output block) for each product
+struct OffW1F { static constexpr int at(int st, int fb) { return (2 * st * kLD1 + 32 * fb) * 4; } };
+struct OffW2F { static constexpr int at(int st, int fb) { return ((32 * (st >> 4) + perm(st & 15)) * kLD2 + 32 * fb) * 4; } };
+struct OffW3F { static constexpr int at(int st, int ob) { return ((32 * (st >> 4) + perm(st & 15)) * kLD3 + 32 * ob) * 4; } };
+struct OffW3B { static constexpr int at(int st, int fb) { return (32 * fb * kLD3 + 32 * (st >> 4) + perm(st & 15)) * 4; } };
+struct OffW2B { static constexpr int at(int st, int fb) { return (32 * fb * kLD2 + 32 * (st >> 4) + perm(st & 15)) * 4; } };
+
+template <int N> struct MlpLds {
+    static constexpr int NP = (N + 3) & ~3;     // W1' rows padded to whole float4s
+    float W1T[kH1 * NP];                        // W1 transposed [feature][k] (16-byte aligned: first member)
+    float W1[N * kLD1];
+    float W2[kH1 * kLD2];
+    float W3[kH2 * kLD3];
+    int next;                                   // next unclaimed tile of this workgroup's range
+};
+
 template <typename S>
-__global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
+__global__ __launch_bounds__(kThreads, kWaves / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
                                                                 const float* __restrict__ W2g, const float* __restrict__ W3g,
                                                                 const float* __restrict__ x, float* __restrict__ Vout,
                                                                 float* __restrict__ gout, int64_t B, int64_t ntiles) {
     constexpr int N = S::N;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
-    __shared__ float sW1[N * kLD1];
-    __shared__ float sW2[kH1 * kLD2];
-    __shared__ float sW3[kH2 * kLD3];
+    constexpr int NP = MlpLds<N>::NP;
+    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    float* const sW1 = L.W1;
+    float* const sW2 = L.W2;
+    float* const sW3 = L.W3;
+    float* const sW1T = L.W1T;
 
     const int tid = threadIdx.x;
+    if (tid == 0) L.next = kWaves;  // tiles 0..kWaves-1 of the range are taken statically
+#ifdef HJBX_DIAG_CLOCK
+    const unsigned long long tentry = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int idx = tid; idx < N * kH1; idx += kThreads) sW1[(idx / kH1) * kLD1 + (idx % kH1)] = W1g[idx];
+    for (int idx = tid; idx < kH1 * NP; idx += kThreads) {
+        const int f = idx / NP, k = idx % NP;
+        sW1T[idx] = k < N ? W1g[k * kH1 + f] : 0.f;
+    }
     for (int idx = tid; idx < kH1 * kH2; idx += kThreads) sW2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
     for (int idx = tid; idx < kH2 * kH3; idx += kThreads) sW3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
     __syncthreads();
@@ -88,42 +164,60 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
     const int h = lane >> 5;  // k parity / accumulator row-half
 
     // lane-dependent LDS bases; everything else is a compile-time offset
-    const float* w1f = sW1 + h * kLD1 + i;          // forward:  W1[2s + h][32 fb + i]
-    const float* w2f = sW2 + 4 * h * kLD2 + i;      //           W2[32 kb + perm(s) + 4h][32 fb + i]
-    const float* w3f = sW3 + 4 * h * kLD3 + i;      //           W3[32 kb + perm(s) + 4h][32 ob + i]
-    const float* w3b = sW3 + i * kLD3 + 4 * h;      // backward: W3[32 fb + i][32 kb + perm(s) + 4h]
-    const float* w2b = sW2 + i * kLD2 + 4 * h;      //           W2[32 fb + i][32 kb + perm(s) + 4h]
-    const float* w1b = sW1 + (i < N ? i : 0) * kLD1 + 4 * h;  //  W1[i][32 kb + perm(s) + 4h], rows >= N are zero
-    const bool w1row = i < N;
+    // (the low 32 bits of a flat pointer into the LDS aperture are the LDS byte address)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)&L;
+    const uint32_t w1f = lds0 + (uint32_t)offsetof(MlpLds<N>, W1) + 4u * (h * kLD1 + i);      // forward:  W1[2s + h][32 fb + i]
+    const uint32_t w2f = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (4 * h * kLD2 + i);  //           W2[32 kb + perm(s) + 4h][32 fb + i]
+    const uint32_t w3f = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (4 * h * kLD3 + i);  //           W3[32 kb + perm(s) + 4h][32 ob + i]
+    const uint32_t w3b = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (i * kLD3 + 4 * h);  // backward: W3[32 fb + i][32 kb + perm(s) + 4h]
+    const uint32_t w2b = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (i * kLD2 + 4 * h);  //           W2[32 fb + i][32 kb + perm(s) + 4h]
+    const float4* w1t = reinterpret_cast<const float4*>(sW1T + 4 * h * NP);  // W1'[32 kb + perm(s) + 4h][0..NP)
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * kWaves) {
+    // Work distribution: the workgroup owns a contiguous range of tiles and its waves pull the next tile from
+    // an LDS counter.  (With a static stride the older wave of each SIMD pair wins the matrix-pipe arbitration,
+    // finishes its share ~25 % early and leaves its partner running alone at ~70 % pipe utilisation.)
+    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t t_end = (t_begin + tiles_per_wg < ntiles) ? t_begin + tiles_per_wg : ntiles;
+    // one row of x per lane; both lane halves read the same row (the second read hits the same lines)
+    auto load_row = [&](int64_t t, float (&dst)[N]) {
+        const int64_t en = t * 32 + i;
+        if (t < t_end && en < B) {
+            if constexpr ((N * 4) % 16 == 0) {
+                const float4* rp = reinterpret_cast<const float4*>(x + en * N);
+#pragma unroll
+                for (int q = 0; q < N / 4; ++q) {
+                    const float4 v = rp[q];
+                    dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+                }
+            } else {
+                const float2* rp2 = reinterpret_cast<const float2*>(x + en * N);
+#pragma unroll
+                for (int q = 0; q < N / 2; ++q) {
+                    const float2 v = rp2[q];
+                    dst[2 * q] = v.x; dst[2 * q + 1] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) dst[k] = p.xf[k];
+        }
+    };
+
+    int64_t tile = t_begin + wave;
+#ifdef HJBX_DIAG_CLOCK
+    // DIAGNOSTIC BUILD ONLY (tools/diag_clock.py): shader-clock and 100 MHz wall stamps around the tile loop
+    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
+#endif
+    float xs[N];
+    load_row(tile, xs);
+    for (; tile < t_end;) {
         // the weights are loop invariant: without this barrier LICM hoists hundreds of LDS reads out of the
         // tile loop into registers and spills them to scratch
         asm volatile("" ::: "memory");
         const int64_t env = tile * 32 + i;
         const bool valid = env < B;
-        float xs[N], e[N], z[N];
-        if (valid) {
-            // both lane halves read the same row (second read hits the same lines)
-            const float4* rp = reinterpret_cast<const float4*>(x + env * N);
-            if constexpr ((N * 4) % 16 == 0) {
-#pragma unroll
-                for (int q = 0; q < N / 4; ++q) {
-                    const float4 v = rp[q];
-                    xs[4 * q] = v.x; xs[4 * q + 1] = v.y; xs[4 * q + 2] = v.z; xs[4 * q + 3] = v.w;
-                }
-            } else {
-                const float2* rp2 = reinterpret_cast<const float2*>(x + env * N);
-#pragma unroll
-                for (int q = 0; q < N / 2; ++q) {
-                    const float2 v = rp2[q];
-                    xs[2 * q] = v.x; xs[2 * q + 1] = v.y;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) xs[k] = p.xf[k];
-        }
+        float e[N], z[N];
         float ee = 0.f;
 #pragma unroll
         for (int k = 0; k < N; ++k) e[k] = xs[k] - p.xf[k];
@@ -133,6 +227,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
             ee += e[k] * e[k];
             z[k] = (e[k] - p.mean[k]) / p.std[k];
         }
+        // claim the next tile now and fetch its row: the HBM latency hides behind this tile's ~50k cycles of MFMAs
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&L.next, 1);
+        const int64_t tile_next = t_begin + __builtin_amdgcn_readfirstlane(nxt);
+        load_row(tile_next, xs);
+
+        // All element-wise work (ReLU, mask building, mask application, 2y, |y|^2) is done lazily inside the
+        // B-operand fetch of the NEXT product, so it issues in the shadow of the 64-cycle MFMAs instead of
+        // forming VALU-only phases between the chains.
 
         // ---- layer 1: H1' (128 x 32) = W1' (128 x N) . Z' (N x 32) --------------------------------------
         f32x16 a1[4];
@@ -140,110 +243,101 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a1[fb][r] = 0.f;
-        mfma_chain<N / 2, 4, 1>(
-            a1, [&](int st, int fb) { return w1f[2 * st * kLD1 + 32 * fb]; }, [&](int st) { return h ? z[2 * st + 1] : z[2 * st]; });
-        uint32_t m1[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                m |= (a1[fb][r] > 0.f ? 1u : 0u) << r;
-                a1[fb][r] = fmaxf(a1[fb][r], 0.f);
-            }
-            m1[fb] = m;
-        }
+        float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
+        mfma_chain<OffW1F, N / 2, 4, 2>(a1, ring4, w1f, [&](int st) { return h ? z[2 * st + 1] : z[2 * st]; });
 
-        // ---- layer 2: H2' (128 x 32) = W2' . H1' ----------------------------------------------------------
+        // ---- layer 2: H2' (128 x 32) = W2' . relu(H1') ---------------------------------------------------
         f32x16 a2[4];
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[fb][r] = 0.f;
-        mfma_chain<64, 4, 1>(
-            a2, [&](int st, int fb) { return w2f[(32 * (st >> 4) + perm(st & 15)) * kLD2 + 32 * fb]; },
-            [&](int st) { return a1[st >> 4][st & 15]; });
-        uint32_t m2[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                m |= (a2[fb][r] > 0.f ? 1u : 0u) << r;
-                a2[fb][r] = fmaxf(a2[fb][r], 0.f);
-            }
-            m2[fb] = m;
-        }
+        mfma_chain<OffW2F, 64, 4, 2>(
+            a2, ring4, w2f, [&](int st) { return relu1(a1[st >> 4][st & 15]); });
 
-        // ---- layer 3: Y' (64 x 32) = W3' . H2' ------------------------------------------------------------
+        // ---- layer 3: Y' (64 x 32) = W3' . relu(H2') ------------------------------------------------------
         f32x16 y[2];
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[ob][r] = 0.f;
-        mfma_chain<64, 2, 2>(
-            y, [&](int st, int ob) { return w3f[(32 * (st >> 4) + perm(st & 15)) * kLD3 + 32 * ob]; },
-            [&](int st) { return a2[st >> 4][st & 15]; });
+        mfma_chain<OffW3F, 64, 2, 2>(
+            y, ring2, w3f, [&](int st) { return relu1(a2[st >> 4][st & 15]); });
 
         float vpart = 0.f;
+        if (!gout) {  // value only
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+            for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                vpart += y[ob][r] * y[ob][r];
-                y[ob][r] = 2.f * y[ob][r];  // dV/dy
-            }
-        const float vsum = vpart + __shfl_xor(vpart, 32, 64);
-        if (Vout && valid && h == 0) Vout[env] = vsum + p.eps_s * ee;
-        if (!gout) continue;
+                for (int r = 0; r < 16; ++r) vpart += y[ob][r] * y[ob][r];
+            const float vs = vpart + __shfl_xor(vpart, 32, 64);
+            if (valid && h == 0) Vout[env] = vs + p.eps_s * ee;
+            tile = tile_next;
+            continue;
+        }
 
-        // ---- backward 3: dH2' (128 x 32) = W3 (128 x 64) . dY' (64 x 32), masked by h2 > 0 ------------------
+        // ---- backward 3: dH2' (128 x 32) = W3 (128 x 64) . (2 Y') -------------------------------------------
         f32x16 d2[4];
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[fb][r] = 0.f;
-        mfma_chain<32, 4, 1>(
-            d2, [&](int st, int fb) { return w3b[32 * fb * kLD3 + 32 * (st >> 4) + perm(st & 15)]; },
-            [&](int st) { return y[st >> 4][st & 15]; });
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d2[fb][r] = ((m2[fb] >> r) & 1u) ? d2[fb][r] : 0.f;
+        mfma_chain<OffW3B, 32, 4, 2>(
+            d2, ring4, w3b, [&](int st) {
+                const float v = y[st >> 4][st & 15];
+                vpart += v * v;
+                return 2.f * v;  // dV/dy
+            });
+#ifndef HJBX_DIAG_CLOCK
+        if (Vout) {
+            const float vs = vpart + __shfl_xor(vpart, 32, 64);
+            if (valid && h == 0) Vout[env] = vs + p.eps_s * ee;
+        }
+#endif
 
-        // ---- backward 2: dH1' (128 x 32) = W2 . dH2', masked by h1 > 0 -------------------------------------
+        // ---- backward 2: dH1' (128 x 32) = W2 . (dH2' . [h2 > 0]) -------------------------------------------
+        // (the pre-activations a2 are still in registers: compare + select per element, no mask words to build)
         f32x16 d1[4];
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[fb][r] = 0.f;
-        mfma_chain<64, 4, 1>(
-            d1, [&](int st, int fb) { return w2b[32 * fb * kLD2 + 32 * (st >> 4) + perm(st & 15)]; },
-            [&](int st) { return d2[st >> 4][st & 15]; });
+        mfma_chain<OffW2B, 64, 4, 2>(
+            d1, ring4, w2b, [&](int st) { return a2[st >> 4][st & 15] > 0.f ? d2[st >> 4][st & 15] : 0.f; });
+
+        // ---- backward 1: dZ' (N x 32) = W1 (N x 128) . (dH1' . [h1 > 0]) on the VALU ---------------------------
+        // Only N of an MFMA tile's 32 rows would be useful here (7.6 % of all MFMA time for n = 4); instead
+        // each lane dots its 64 resident features with W1' rows (wave-uniform float4 LDS broadcasts), the two
+        // lane halves are added with one cross-half shuffle per row, and the matrix pipe stays free for the
+        // partner wave.
+        // [h1 > 0] is re-derived by recomputing layer 1 (N/2 x 4 MFMAs, 1 % of the tile): cheaper in issue slots
+        // than building and carrying 128 mask bits per lane through the forward pass.
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1[fb][r] = ((m1[fb] >> r) & 1u) ? d1[fb][r] : 0.f;
-
-        // ---- backward 1: dZ' (N x 32, padded to 32 rows) = W1 (N x 128) . dH1' ------------------------------
-        f32x16 dzv[1];
+            for (int r = 0; r < 16; ++r) a1[fb][r] = 0.f;
+        mfma_chain<OffW1F, N / 2, 4, 2>(a1, ring4, w1f, [&](int st) { return h ? z[2 * st + 1] : z[2 * st]; });
+        float part[NP];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dzv[0][r] = 0.f;
-        mfma_chain<64, 1, 4>(
-            dzv, [&](int st, int) { const float wv = w1b[32 * (st >> 4) + perm(st & 15)]; return w1row ? wv : 0.f; },
-            [&](int st) { return d1[st >> 4][st & 15]; });
-        const f32x16 dz = dzv[0];
-
-        // row k of dZ' sits in register (k&3) + 4(k>>3) of lane-half (k>>2)&1; gather the N rows on half 0
+        for (int k = 0; k < NP; ++k) part[k] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float dv = a1[kb][s] > 0.f ? d1[kb][s] : 0.f;
+#pragma unroll
+                for (int q = 0; q < NP / 4; ++q) {
+                    const float4 w = w1t[(32 * kb + perm(s)) * (NP / 4) + q];
+                    part[4 * q + 0] += w.x * dv;
+                    part[4 * q + 1] += w.y * dv;
+                    part[4 * q + 2] += w.z * dv;
+                    part[4 * q + 3] += w.w * dv;
+                }
+            }
         float g[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int rk = (k & 3) + 4 * (k >> 3);
-            const float own = dz[rk];
-            const float other = __shfl_xor(own, 32, 64);
-            const float v = (((k >> 2) & 1) == 0) ? own : other;
+            const float v = part[k] + __shfl_xor(part[k], 32, 64);
             g[k] = v / p.std[k] + 2.f * p.eps_s * e[k];
         }
         if (valid && h == 0) {
@@ -257,7 +351,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_value_grad_mfma(S sys, MlpP<S::
                 for (int q = 0; q < N / 2; ++q) op[q] = make_float2(g[2 * q], g[2 * q + 1]);
             }
         }
+        tile = tile_next;
     }
+#ifdef HJBX_DIAG_CLOCK
+    {
+        const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
+        // the caller of the diagnostic build passes a scratch "V" buffer of >= 4*gridDim.x*kWaves floats and gradV != NULL
+        if (Vout && gout && lane == 0) {
+            float* d = Vout + 4 * ((int64_t)blockIdx.x * kWaves + wave);
+            d[0] = (float)(t1c - t0c); d[1] = (float)(t1r - t0r);
+            d[2] = (float)(t0r - tentry); d[3] = (float)(tentry & 0xFFFFFFull);
+        }
+    }
+#endif
 }
 
 template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* st) {
