@@ -179,10 +179,13 @@ size_t hjbx_reduce_workspace_bytes(void);
        live.  A live env outside the observation box (or t==T) emits (cost=e'Pe, done=1), latches    \
        done_step=t and holds its state; otherwise u from gradV, cost=l(x,u)*dt, done=0, x_next=       \
        simulate(x,u).  Dead envs emit cost=0, done=0 and hold.  done_step (B,) int32 must be          \
-       initialised to -1 before t=0.  u_out may be NULL. */                                           \
+       initialised to -1 before t=0.  u_out may be NULL.  resid_t (B,) may be NULL; when given it     \
+       receives the normalised HJB residual gradV.xdot/(l+eps) + 1 (vhjb.py:233, signed, before the   \
+       abs) of every live, non-terminating environment at its current state and 0 elsewhere -- the    \
+       residual comes for free here because u, xdot and l are already in registers. */                \
     int hjbx_vhjb_step_##SFX(const hjbx_system* sys, const hjbx_task* task, int integrator, int t,    \
                              int T_max, const T* x, const T* gradV, T* x_next, T* u_out, T* cost_t,   \
-                             T* done_t, int32_t* done_step, int64_t B, void* stream);                 \
+                             T* done_t, int32_t* done_step, T* resid_t, int64_t B, void* stream);     \
     /* Controller.get_control_efforts for the closed-form controllers, u (B,m). */      \
     int hjbx_controller_##SFX(const hjbx_system* sys, const hjbx_controller* ctrl, const T* x, T* u,  \
                               int64_t B, void* stream);                                               \

@@ -227,14 +227,14 @@ def value_grad(sys, mlp, W1, W2, W3, x, dtype=np.float64):
 
 
 def vhjb_step(sys, task, step, T_max, x, g, done_step, integrator=0, dtype=np.float64):
-    """-> x_next, u, cost_t, done_t, done_step(updated copy)"""
+    """-> x_next, u, cost_t, done_t, done_step(updated copy), resid_t"""
     sfx, dt = _dt(dtype)
     x = _a(x, dt, (-1, sys.n)); g = _a(g, dt, (-1, sys.n)); B = x.shape[0]
     ds = np.ascontiguousarray(done_step, np.int32).copy()
-    xn = np.empty_like(x); u = np.empty((B, sys.m), dt); c = np.empty((B,), dt); d = np.empty((B,), dt)
+    xn = np.empty_like(x); u = np.empty((B, sys.m), dt); c = np.empty((B,), dt); d = np.empty((B,), dt); rs = np.empty((B,), dt)
     getattr(lib(), f"orc_vhjb_step_{sfx}")(_r(sys.c), _r(task), C.c_int(integrator), C.c_int(step), C.c_int(T_max), _p(x), _p(g), _p(xn),
-                                          _p(u), _p(c), _p(d), _p(ds), C.c_int64(B))
-    return xn, u, c, d, ds
+                                          _p(u), _p(c), _p(d), _p(ds), _p(rs), C.c_int64(B))
+    return xn, u, c, d, ds, rs
 
 
 def vhjb_rollout(sys, task, mlp, W1, W2, W3, x0, T_max, integrator=0, dtype=np.float64, log=True):

@@ -487,14 +487,15 @@ void FN(orc_value_grad)(const orc_system* s, const orc_mlp* p, const REAL* W1, c
 /* One iteration of rollout_trajectory (vhjb.py:175-191) for every env, given gradV of the current
  * states: the batch twin of hjbx_vhjb_step (semantics in include/hjbx.h). PARITY UNPINNED. */
 void FN(orc_vhjb_step)(const orc_system* s, const hjbx_task* t, int integrator, int step, int T_max, const REAL* x,
-                       const REAL* g, REAL* xn, REAL* u_out, REAL* cost_t, REAL* done_t, int32_t* done_step, int64_t B) {
+                       const REAL* g, REAL* xn, REAL* u_out, REAL* cost_t, REAL* done_t, int32_t* done_step, REAL* resid_t,
+                       int64_t B) {
     const int n = s->n, m = s->m;
     for (int64_t b = 0; b < B; ++b) {
         const REAL* xb = x + b * n;
         REAL xo[HJBX_MAX_N], u[HJBX_MAX_M];
         for (int i = 0; i < n; ++i) xo[i] = xb[i];
         for (int j = 0; j < m; ++j) u[j] = 0;
-        REAL c = 0, d = 0;
+        REAL c = 0, d = 0, res = 0;
         if (done_step[b] < 0) {
             if (step >= T_max || FN(out_of_box)(s, t, xb)) {
                 c = FN(termination_cost1)(s, t, xb); d = 1; done_step[b] = step;
@@ -502,13 +503,22 @@ void FN(orc_vhjb_step)(const orc_system* s, const hjbx_task* t, int integrator, 
                 REAL f1[HJBX_MAX_N], f2[HJBX_MAX_N * HJBX_MAX_M], ur[HJBX_MAX_M];
                 FN(affine1)(s, xb, f1, f2);
                 FN(control_from_grad1)(s, t, f2, g + b * n, ur, u);
-                c = FN(running_cost1)(s, t, xb, u) * (REAL)s->dt;
+                const REAL l = FN(running_cost1)(s, t, xb, u);
+                c = l * (REAL)s->dt;
+                REAL vdot = 0;   /* vhjb.py:231-233, signed residual before the abs */
+                for (int i = 0; i < n; ++i) {
+                    REAL acc = 0;
+                    for (int j = 0; j < m; ++j) acc += f2[i * m + j] * u[j];
+                    vdot += g[b * n + i] * (f1[i] + acc);
+                }
+                res = vdot / (l + (REAL)t->eps) + 1;
                 FN(simulate1)(s, integrator, xb, u, xo);
             }
         }
         for (int i = 0; i < n; ++i) xn[b * n + i] = xo[i];
         if (u_out) for (int j = 0; j < m; ++j) u_out[b * m + j] = u[j];
         cost_t[b] = c; done_t[b] = d;
+        if (resid_t) resid_t[b] = res;
     }
 }
 

@@ -159,7 +159,7 @@ def _typed_signatures():
         "control_from_grad": [P, P, P, P, P, _I64, P],
         "hjb_residual": [P, P, _I32, P, P, P, P, P, P, P, _I64, P],
         "termination_residual": [_DBL, P, P, P, P, P, P, P, _I64, P],
-        "vhjb_step": [P, P, _I32, _I32, _I32, P, P, P, P, P, P, P, _I64, P],
+        "vhjb_step": [P, P, _I32, _I32, _I32, P, P, P, P, P, P, P, P, _I64, P],
         "controller": [P, P, P, P, _I64, P],
         "rollout_feedback": [P, P, P, _I32, _U32, _I32, P, P, P, P, P, P, P, _I64, P],
     }

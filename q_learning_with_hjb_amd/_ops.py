@@ -166,7 +166,7 @@ def termination_residual(eps, V, cost, done, want_loss=True, want_grad=True, wan
     return li, dv, sums
 
 
-def vhjb_step(sys, task, t, T_max, x, grad_v, x_next, cost_t, done_t, done_step, u_out=None, integrator=_abi.EULER):
+def vhjb_step(sys, task, t, T_max, x, grad_v, x_next, cost_t, done_t, done_step, u_out=None, integrator=_abi.EULER, resid_t=None):
     B = x.shape[0]
     _chk(x, "x", (B, sys.n))
     _chk(grad_v, "grad_v", (B, sys.n), x.dtype)
@@ -176,8 +176,10 @@ def vhjb_step(sys, task, t, T_max, x, grad_v, x_next, cost_t, done_t, done_step,
     _chk(done_step, "done_step", (B,), torch.int32)
     if u_out is not None:
         _chk(u_out, "u_out", (B, sys.m), x.dtype)
+    if resid_t is not None:
+        _chk(resid_t, "resid_t", (B,), x.dtype)
     check(_fn("vhjb_step", x)(sys.ptr, ref(task), int(integrator), int(t), int(T_max), _p(x), _p(grad_v), _p(x_next), _p(u_out),
-                              _p(cost_t), _p(done_t), _p(done_step), B, _stream()))
+                              _p(cost_t), _p(done_t), _p(done_step), _p(resid_t), B, _stream()))
 
 
 def controller(sys, ctrl, x):

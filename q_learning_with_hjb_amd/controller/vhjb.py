@@ -349,11 +349,12 @@ class VHJBController(Controller):
 
     # -- rollouts --------------------------------------------------------------------------------------
     @torch.no_grad()
-    def rollout_batch(self, x0: torch.Tensor, max_steps: Optional[int] = None, log_u: bool = False):
+    def rollout_batch(self, x0: torch.Tensor, max_steps: Optional[int] = None, log_u: bool = False, log_residual: bool = False):
         """B closed loops in lock-step (the batch twin of rollout_trajectory, vhjb.py:171-193).
 
         x0 (B, n) on the device.  Returns time-major device tensors: traj (T+1, B, n), cost (T+1, B),
-        done (T+1, B), done_step (B,) int32 [index of each env's terminal tuple], u (T, B, m) | None.
+        done (T+1, B), done_step (B,) int32 [index of each env's terminal tuple], u (T, B, m) | None,
+        residual (T+1, B) | None [signed normalised HJB residual along the trajectories, a by-product of the step kernel].
         Tuple t of env b is valid iff t <= done_step[b]."""
         T = self.maximum_timestep if max_steps is None else int(max_steps)
         x0 = x0.to(dtype=self.dtype, device=self.device).contiguous()
@@ -363,6 +364,7 @@ class VHJBController(Controller):
         cost = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)
         done = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)
         ulog = torch.empty((T, B, self.control_dim), dtype=self.dtype, device=self.device) if log_u else None
+        resid = torch.empty((T + 1, B), dtype=self.dtype, device=self.device) if log_residual else None
         done_step = torch.full((B,), -1, dtype=torch.int32, device=self.device)
         traj[0].copy_(x0)
         g = None
@@ -370,8 +372,9 @@ class VHJBController(Controller):
             if t < T or g is None:
                 g = self.get_v_gradient(traj[t])
             _ops.vhjb_step(sysh, task, t, T, traj[t], g, traj[t + 1], cost[t], done[t], done_step,
-                           u_out=(ulog[t] if (log_u and t < T) else None), integrator=integ)
-        return dict(traj=traj[:T + 1], cost=cost, done=done, done_step=done_step, u=ulog)
+                           u_out=(ulog[t] if (log_u and t < T) else None), integrator=integ,
+                           resid_t=(resid[t] if log_residual else None))
+        return dict(traj=traj[:T + 1], cost=cost, done=done, done_step=done_step, u=ulog, residual=resid)
 
     def rollout_trajectory(self) -> List[Tuple[np.ndarray, float, float]]:
         """One trajectory as the reference returns it: a list of (x, cost, done) tuples."""

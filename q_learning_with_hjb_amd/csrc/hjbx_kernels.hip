@@ -337,7 +337,7 @@ template <int INTEG, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim, int t, int T_max,
                                                       const T* x, const T* __restrict__ g, T* xn, T* __restrict__ u_out,
                                                       T* __restrict__ cost_t, T* __restrict__ done_t,
-                                                      int32_t* __restrict__ done_step, int64_t B) {
+                                                      int32_t* __restrict__ done_step, T* __restrict__ resid_t, int64_t B) {
     constexpr int N = S::N, M = S::M;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= B) return;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M
     for (int k = 0; k < N; ++k) xo[k] = xs[k];
 #pragma unroll
     for (int j = 0; j < M; ++j) u[j] = T(0);
-    T c = T(0), d = T(0);
+    T c = T(0), d = T(0), res = T(0);
     if (ds < 0) {
         T e[N];
         error_coords(sys, tk.xf, xs, e);
@@ -361,7 +361,19 @@ __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M
             T f1[N], f2[N * M], ur[M];
             sys.affine(xs, f1, f2);
             control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
-            c = running_cost_e<S, T>(tk, e, u) * lim.dt;
+            const T l = running_cost_e<S, T>(tk, e, u);
+            c = l * lim.dt;
+            if (resid_t) {  // vhjb.py:231-233: gradV . (f1 + f2 u) / (l + eps) + 1
+                T vdot = T(0);
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    T a = T(0);
+#pragma unroll
+                    for (int j = 0; j < M; ++j) a += f2[r * M + j] * u[j];
+                    vdot += gs[r] * (f1[r] + a);
+                }
+                res = vdot / (l + tk.eps) + T(1);
+            }
             integrate<INTEG>(sys, lim.dt, xs, u, xo);
         }
     }
@@ -369,6 +381,7 @@ __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M
     if (u_out) RowIO<T, M>::store(u_out, i, u);
     cost_t[i] = c;
     done_t[i] = d;
+    if (resid_t) resid_t[i] = res;
 }
 
 template <int INTEG, int CK, typename S, typename T>
@@ -653,7 +666,7 @@ static int termination_residual_impl(double eps, const T* V, const T* cost, cons
 
 template <typename T>
 static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int integ, int t, int T_max, const T* x, const T* g,
-                          T* xn, T* u_out, T* cost_t, T* done_t, int32_t* done_step, int64_t B, void* st) {
+                          T* xn, T* u_out, T* cost_t, T* done_t, int32_t* done_step, T* resid_t, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL");
     HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
     HJBX_REQUIRE(t >= 0 && T_max >= 0, "negative step index");
@@ -665,10 +678,10 @@ static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int int
             auto lim = make_limits<T, SS::M>(sys);
             if (integ == HJBX_EULER)
                 hipLaunchKernelGGL((k_vhjb_step<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
-                                   g, xn, u_out, cost_t, done_t, done_step, B);
+                                   g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
             else
                 hipLaunchKernelGGL((k_vhjb_step<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
-                                   g, xn, u_out, cost_t, done_t, done_step, B);
+                                   g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
         })) return unsupported(sys);
     return check_launch("hjbx_vhjb_step");
 }
@@ -836,7 +849,7 @@ int hjbx_dims(const hjbx_system* sys, int* n, int* m) {
     int hjbx_control_from_grad_##SFX(const hjbx_system* s, const hjbx_task* t, const T* x, const T* g, T* u, int64_t B, void* st) { return control_from_grad_impl<T>(s, t, x, g, u, B, st); } \
     int hjbx_hjb_residual_##SFX(const hjbx_system* s, const hjbx_task* t, int mode, const T* x, const T* g, const T* done, T* li, T* dg, T* sums, void* ws, int64_t B, void* st) { return hjb_residual_impl<T>(s, t, mode, x, g, done, li, dg, sums, ws, B, st); } \
     int hjbx_termination_residual_##SFX(double eps, const T* V, const T* cost, const T* done, T* li, T* dV, T* sums, void* ws, int64_t B, void* st) { return termination_residual_impl<T>(eps, V, cost, done, li, dV, sums, ws, B, st); } \
-    int hjbx_vhjb_step_##SFX(const hjbx_system* s, const hjbx_task* t, int integ, int step, int T_max, const T* x, const T* g, T* xn, T* uo, T* c, T* d, int32_t* ds, int64_t B, void* st) { return vhjb_step_impl<T>(s, t, integ, step, T_max, x, g, xn, uo, c, d, ds, B, st); } \
+    int hjbx_vhjb_step_##SFX(const hjbx_system* s, const hjbx_task* t, int integ, int step, int T_max, const T* x, const T* g, T* xn, T* uo, T* c, T* d, int32_t* ds, T* rs, int64_t B, void* st) { return vhjb_step_impl<T>(s, t, integ, step, T_max, x, g, xn, uo, c, d, ds, rs, B, st); } \
     int hjbx_controller_##SFX(const hjbx_system* s, const hjbx_controller* c, const T* x, T* u, int64_t B, void* st) { return controller_impl<T>(s, c, x, u, B, st); } \
     int hjbx_rollout_feedback_##SFX(const hjbx_system* s, const hjbx_task* t, const hjbx_controller* c, int integ, uint32_t flags, int T_steps, const T* x0, T* traj, T* ul, T* cost, int32_t* ds, T* tc, T* xf, int64_t B, void* st) { return rollout_feedback_impl<T>(s, t, c, integ, flags, T_steps, x0, traj, ul, cost, ds, tc, xf, B, st); }
 

@@ -345,9 +345,9 @@ def test_vhjb_step_sequence(name, prec):
         g = rng.standard_normal((B, n)) * 5
         gd = dev(g, tdt); gr = gd.cpu().numpy().astype(np.float64)
         xn = torch.empty_like(xd); c = torch.empty(B, dtype=tdt, device="cuda"); dn = torch.empty_like(c)
-        uo = torch.empty((B, m), dtype=tdt, device="cuda")
-        _ops.vhjb_step(d.system, task, t, T, xd, gd, xn, c, dn, ds_d, u_out=uo)
-        oxn, ou, oc, od, ds_o = O.vhjb_step(s, task, t, T, xo, gr, ds_o)
+        uo = torch.empty((B, m), dtype=tdt, device="cuda"); rs = torch.empty(B, dtype=tdt, device="cuda")
+        _ops.vhjb_step(d.system, task, t, T, xd, gd, xn, c, dn, ds_d, u_out=uo, resid_t=rs)
+        oxn, ou, oc, od, ds_o, ors = O.vhjb_step(s, task, t, T, xo, gr, ds_o)
         if prec == "f64":
             assert np.array_equal(ds_d.cpu().numpy(), ds_o)
         else:
@@ -361,6 +361,7 @@ def test_vhjb_step_sequence(name, prec):
         check(xn[km], oxn[keep], tol * 4, np.abs(xo).max(), angle_idx=ANGLE_IDX[name])
         check(c[km], oc[keep], tol * 4, np.abs(oc).max() + 1)
         check(uo[km], ou[keep], tol * 4, np.abs(d.umax).max())
+        check(rs[km], ors[keep], tol * 8, np.abs(ors).max() + 1)            # fused HJB residual by-product
         assert np.array_equal(dn[km].cpu().numpy().astype(np.float64), od[keep])
         xd = xn; xo = xn.cpu().numpy().astype(np.float64) if prec == "f32" else oxn
         if prec == "f64":
