@@ -6,17 +6,22 @@
 //   dV/dx = ((((2y) W3') . [h2>0]) W2' . [h1>0]) W1' / std + 2 eps_s e
 //
 // Design (CDNA4):
-//  * v_mfma_f32_32x32x2_f32 (exact f32, 155 TFLOP/s dense) -- the network is float32 in the reference.
-//  * Everything is computed TRANSPOSED (features x environments): a wave owns a tile of 32
-//    environments (the MFMA column index = lane & 31) and the accumulator registers of one layer ARE
-//    the B operands of the next one, forward and backward, with no cross-lane movement and no LDS
-//    round trip: accumulator register s of lane-half h holds feature perm(s) + 4h, and the weight (A)
-//    operand for k-step s is simply fetched for that same feature.
-//  * All three weight matrices live in LDS once per workgroup (104 KB, one copy serves W and W'):
-//    rows padded to an ODD stride (129 / 65 floats) so that both the row-walk of the forward pass
-//    and the column-walk of the backward pass hit 32 distinct banks per ds_read_b32 lane group.
-//  * Persistent grid: one 512-thread workgroup per CU (two waves per SIMD share the matrix pipe, one
-//    computes while the other waits on LDS); every wave strides over environment tiles.
+//  * v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s dense peak) -- the network is float32 in the reference.
+//  * Everything is computed TRANSPOSED (features x environments): a wave owns TL tiles of 32 environments
+//    (the MFMA column index = lane & 31) and the accumulator registers of one layer ARE the B operands of
+//    the next one, forward and backward, with no cross-lane movement and no LDS round trip: accumulator
+//    register s of lane-half h holds feature perm(s) + 4h, and the weight (A) operand for k-step s is
+//    simply fetched for that same feature.
+//  * All three weight matrices live in LDS once per workgroup (106 KB, one copy serves W and W'): rows
+//    padded to an ODD stride (129 / 65 floats) so that both the row walk of the forward pass and the
+//    column walk of the backward pass hit 32 distinct banks per ds_read_b32 lane group.
+//  * Every instruction issued between two MFMAs costs matrix-pipe time here (measured ~4 cycles each,
+//    tools/ubench/mfma_mix.hip), so: weight operands are prefetched by inline-asm ds_reads two k-steps
+//    ahead and retired by counted s_waitcnt; ReLU is one integer max; the ReLU masks are not stored (the
+//    pre-activations stay in registers / layer 1 is recomputed); the last backward product (only n useful
+//    rows) runs on the VALU; and with TL = 2 each fetched weight feeds two MFMAs.
+//  * Persistent grid, one workgroup per CU; waves pull tile groups from an LDS counter so SIMD partners
+//    finish together.
 // Per environment: 4(128 n + 128*128 + 128*64) flop; algorithmic HBM traffic 4(2n+1) bytes -> MFMA bound.
 #include <hip/hip_runtime.h>
 
@@ -31,11 +36,15 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static constexpr int kH1 = 128, kH2 = 128, kH3 = 64;
 static constexpr int kLD1 = 129, kLD2 = 129, kLD3 = 65;  // odd LDS row strides (floats)
+
+// launch shape: TL tiles of 32 environments per wave, WAVES waves per workgroup (one workgroup per CU).
+//   (TL, WAVES) = (1, 8): two waves per SIMD, 256 VGPRs each.   (2, 4): one wave per SIMD, 512 VGPRs.
+#ifndef HJBX_MLP_TL
+#define HJBX_MLP_TL 1
+#endif
 #ifndef HJBX_MLP_WAVES
 #define HJBX_MLP_WAVES 8
 #endif
-static constexpr int kWaves = HJBX_MLP_WAVES;             // 8 waves = 512 threads: 2 waves per SIMD
-static constexpr int kThreads = kWaves * 64;
 
 template <int N> struct MlpP { float mean[N], std[N], xf[N], eps_s; };
 
@@ -44,38 +53,30 @@ __device__ __forceinline__ constexpr int perm(int s) { return (s & 3) + 8 * (s >
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// relu as ONE instruction: fmaxf / fmed3f compile to a canonicalising v_max plus the v_max, and every instruction
-// issued between two MFMAs of this kernel costs matrix-pipe time (tools/ubench/mfma_mix.hip: ~4 cycles each).
-// max on the raw bits as a signed integer is the same function (negative floats and -0.0 have the sign bit set
-// -> 0; positive floats and +NaN pass through) and stays visible to the compiler's MFMA hazard padding, which an
-// inline-asm v_max_f32 would not.
+// relu as ONE instruction: fmaxf / fmed3f compile to a canonicalising v_max plus the v_max.  max on the raw
+// bits as a signed integer is the same function (negative floats and -0.0 have the sign bit set -> 0; positive
+// floats and +NaN pass through) and stays visible to the compiler's MFMA hazard padding, which an inline-asm
+// v_max_f32 would not.
 __device__ __forceinline__ float relu1(float v) {
     const int b = __builtin_bit_cast(int, v);
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
-
 // ---- software-pipelined MFMA chain ------------------------------------------------------------------------
-// One GEMM of the chain: acc[o] += A_o(step) x b(step), step = 0..NSTEPS-1, o = 0..NOUT-1, where every A operand
-// is one LDS dword per lane.  hipcc sinks compiler-visible ds_reads down to their MFMAs and re-uses two operand
-// registers (read -> lgkmcnt(0) -> 2 MFMAs: 77 % pipe utilisation for a lone wave), whatever the source order or
-// sched_barrier placement.  So the reads are issued from inline asm DEPTH steps ahead and retired with counted
-// s_waitcnt lgkmcnt(N) statements that name their destination registers (guide 5.7, form ii): LDS returns in
-// order, so "at most N newer operations outstanding" means this step's operands have landed.  Any LDS / SMEM
-// operation the compiler adds in between only makes the count conservative.
+// One GEMM of the chain: acc[t][o] += A_o(step) x b_t(step), step = 0..NSTEPS-1, o = 0..NOUT-1 output blocks,
+// t = 0..TL-1 environment tiles; every A operand is one LDS dword per lane.  hipcc sinks compiler-visible
+// ds_reads down to their MFMAs and re-uses two operand registers (read -> lgkmcnt(0) -> 2 MFMAs), whatever the
+// source order or sched_barrier placement.  So the reads are issued from inline asm DEPTH steps ahead and
+// retired with counted s_waitcnt lgkmcnt(N) statements that name their destination registers (guide 5.7,
+// form ii): LDS returns in order, so "at most N newer operations outstanding" means this step's operands have
+// landed.  Any LDS / SMEM operation the compiler adds in between only makes the count conservative.
 template <int BYTE_OFF> __device__ __forceinline__ float lds_read_b32(uint32_t addr) {
     static_assert(BYTE_OFF >= 0 && BYTE_OFF < 65536, "ds_read_b32 offset field is 16 bits");
     float v;
-#ifdef HJBX_DIAG_NOLDS  // diagnostic: matrix-pipe ceiling of this kernel structure without its LDS traffic (wrong results)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(addr));
-#else
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(BYTE_OFF));
-#endif
     return v;
 }
-template <int CNT> __device__ __forceinline__ void lds_wait(float& a) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(CNT));
-}
+template <int CNT> __device__ __forceinline__ void lds_wait(float& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(CNT)); }
 template <int CNT> __device__ __forceinline__ void lds_wait(float& a, float& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(CNT));
 }
@@ -90,15 +91,15 @@ template <typename Off, int ST, int NOUT, int O = 0> __device__ __forceinline__ 
     }
 }
 
-template <typename Off, int NSTEPS, int NOUT, int DEPTH, int ST = 0, typename GetB>
-__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NOUT], float (&ring)[DEPTH + 1][NOUT], uint32_t base, GetB getB) {
+template <typename Off, int NSTEPS, int NOUT, int DEPTH, int TL, int ST = 0, typename GetB>
+__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[TL][NOUT], float (&ring)[DEPTH + 1][NOUT], uint32_t base, GetB getB) {
     static_assert(NOUT == 1 || NOUT == 2 || NOUT == 4, "");
     static_assert(NOUT * DEPTH <= 15, "lgkmcnt is a 4-bit field");
+    static_assert(DEPTH <= 3, "");
     if constexpr (ST == 0) {  // prologue: the first DEPTH steps' operands
         if constexpr (0 < DEPTH && 0 < NSTEPS) chain_issue<Off, 0, NOUT>(ring[0], base);
         if constexpr (1 < DEPTH && 1 < NSTEPS) chain_issue<Off, 1, NOUT>(ring[1], base);
         if constexpr (2 < DEPTH && 2 < NSTEPS) chain_issue<Off, 2, NOUT>(ring[2], base);
-        static_assert(DEPTH <= 3, "");
     }
     if constexpr (ST < NSTEPS) {
         if constexpr (ST + DEPTH < NSTEPS) chain_issue<Off, ST + DEPTH, NOUT>(ring[(ST + DEPTH) % (DEPTH + 1)], base);
@@ -107,11 +108,15 @@ __device__ __forceinline__ void mfma_chain(f32x16 (&acc)[NOUT], float (&ring)[DE
         if constexpr (NOUT == 1) lds_wait<ahead>(cur[0]);
         if constexpr (NOUT == 2) lds_wait<ahead>(cur[0], cur[1]);
         if constexpr (NOUT == 4) lds_wait<ahead>(cur[0], cur[1], cur[2], cur[3]);
-        const float b = getB(ST);
+        float b[TL];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) acc[o] = MFMA(cur[o], b, acc[o]);
+        for (int t = 0; t < TL; ++t) b[t] = getB(ST, t);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int t = 0; t < TL; ++t) acc[t][o] = MFMA(cur[o], b[t], acc[t][o]);
         __builtin_amdgcn_sched_barrier(0);  // keep this step's MFMAs in front of the next step's reads and wait
-        mfma_chain<Off, NSTEPS, NOUT, DEPTH, ST + 1>(acc, ring, base, getB);
+        mfma_chain<Off, NSTEPS, NOUT, DEPTH, TL, ST + 1>(acc, ring, base, getB);
     }
 }
 
@@ -123,40 +128,46 @@ struct OffW3B { static constexpr int at(int st, int fb) { return (32 * fb * kLD3
 struct OffW2B { static constexpr int at(int st, int fb) { return (32 * fb * kLD2 + 32 * (st >> 4) + perm(st & 15)) * 4; } };
 
 template <int N> struct MlpLds {
-    static constexpr int NP = (N + 3) & ~3;     // W1' rows padded to whole float4s
-    float W1T[kH1 * NP];                        // W1 transposed [feature][k] (16-byte aligned: first member)
+    static constexpr int NP = (N + 3) & ~3;  // W1' rows padded to whole float4s
+    float W1T[kH1 * NP];                     // W1 transposed [feature][k] (16-byte aligned: first member)
     float W1[N * kLD1];
     float W2[kH1 * kLD2];
     float W3[kH2 * kLD3];
-    int next;                                   // next unclaimed tile of this workgroup's range
+    int next;                                // next unclaimed tile group of this workgroup's range
 };
 
-template <typename S>
-__global__ __launch_bounds__(kThreads, kWaves / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
-                                                                const float* __restrict__ W2g, const float* __restrict__ W3g,
-                                                                const float* __restrict__ x, float* __restrict__ Vout,
-                                                                float* __restrict__ gout, int64_t B, int64_t ntiles) {
+template <int TL, int NOUT> __device__ __forceinline__ void zero_acc(f32x16 (&a)[TL][NOUT]) {
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[t][o][r] = 0.f;
+}
+
+template <typename S, int TL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
+                                                                         const float* __restrict__ W2g, const float* __restrict__ W3g,
+                                                                         const float* __restrict__ x, float* __restrict__ Vout,
+                                                                         float* __restrict__ gout, int64_t B, int64_t ngroups) {
     constexpr int N = S::N;
+    constexpr int THREADS = WAVES * 64;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
     constexpr int NP = MlpLds<N>::NP;
     __shared__ __attribute__((aligned(16))) MlpLds<N> L;
-    float* const sW1 = L.W1;
-    float* const sW2 = L.W2;
-    float* const sW3 = L.W3;
-    float* const sW1T = L.W1T;
 
     const int tid = threadIdx.x;
-    if (tid == 0) L.next = kWaves;  // tiles 0..kWaves-1 of the range are taken statically
+    if (tid == 0) L.next = WAVES;  // groups 0..WAVES-1 of the range are taken statically
 #ifdef HJBX_DIAG_CLOCK
     const unsigned long long tentry = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int idx = tid; idx < N * kH1; idx += kThreads) sW1[(idx / kH1) * kLD1 + (idx % kH1)] = W1g[idx];
-    for (int idx = tid; idx < kH1 * NP; idx += kThreads) {
+    for (int idx = tid; idx < N * kH1; idx += THREADS) L.W1[(idx / kH1) * kLD1 + (idx % kH1)] = W1g[idx];
+    for (int idx = tid; idx < kH1 * NP; idx += THREADS) {
         const int f = idx / NP, k = idx % NP;
-        sW1T[idx] = k < N ? W1g[k * kH1 + f] : 0.f;
+        L.W1T[idx] = k < N ? W1g[k * kH1 + f] : 0.f;
     }
-    for (int idx = tid; idx < kH1 * kH2; idx += kThreads) sW2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
-    for (int idx = tid; idx < kH2 * kH3; idx += kThreads) sW3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
+    for (int idx = tid; idx < kH1 * kH2; idx += THREADS) L.W2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
+    for (int idx = tid; idx < kH2 * kH3; idx += THREADS) L.W3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -171,194 +182,188 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void k_value_grad_mfma(S sys,
     const uint32_t w3f = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (4 * h * kLD3 + i);  //           W3[32 kb + perm(s) + 4h][32 ob + i]
     const uint32_t w3b = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (i * kLD3 + 4 * h);  // backward: W3[32 fb + i][32 kb + perm(s) + 4h]
     const uint32_t w2b = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (i * kLD2 + 4 * h);  //           W2[32 fb + i][32 kb + perm(s) + 4h]
-    const float4* w1t = reinterpret_cast<const float4*>(sW1T + 4 * h * NP);  // W1'[32 kb + perm(s) + 4h][0..NP)
+    const float4* w1t = reinterpret_cast<const float4*>(L.W1T + 4 * h * NP);                  // W1'[32 kb + perm(s) + 4h][0..NP)
 
-    // Work distribution: the workgroup owns a contiguous range of tiles and its waves pull the next tile from
-    // an LDS counter.  (With a static stride the older wave of each SIMD pair wins the matrix-pipe arbitration,
-    // finishes its share ~25 % early and leaves its partner running alone at ~70 % pipe utilisation.)
-    const int64_t tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg;
-    const int64_t t_end = (t_begin + tiles_per_wg < ntiles) ? t_begin + tiles_per_wg : ntiles;
-    // one row of x per lane; both lane halves read the same row (the second read hits the same lines)
-    auto load_row = [&](int64_t t, float (&dst)[N]) {
-        const int64_t en = t * 32 + i;
-        if (t < t_end && en < B) {
-            if constexpr ((N * 4) % 16 == 0) {
-                const float4* rp = reinterpret_cast<const float4*>(x + en * N);
+    // Work distribution: the workgroup owns a contiguous range of tile groups and its waves pull the next one
+    // from an LDS counter.  (With a static stride the older wave of each SIMD pair wins the matrix-pipe
+    // arbitration, finishes its share ~25 % early and leaves its partner running alone.)
+    const int64_t groups_per_wg = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int64_t g_begin = (int64_t)blockIdx.x * groups_per_wg;
+    const int64_t g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
+
+    // one row of x per lane and tile; both lane halves read the same row (the second read hits the same lines)
+    auto load_rows = [&](int64_t grp, float (&dst)[TL][N]) {
 #pragma unroll
-                for (int q = 0; q < N / 4; ++q) {
-                    const float4 v = rp[q];
-                    dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        for (int t = 0; t < TL; ++t) {
+            const int64_t en = (grp * TL + t) * 32 + i;
+            if (grp < g_end && en < B) {
+                if constexpr ((N * 4) % 16 == 0) {
+                    const float4* rp = reinterpret_cast<const float4*>(x + en * N);
+#pragma unroll
+                    for (int q = 0; q < N / 4; ++q) {
+                        const float4 v = rp[q];
+                        dst[t][4 * q] = v.x; dst[t][4 * q + 1] = v.y; dst[t][4 * q + 2] = v.z; dst[t][4 * q + 3] = v.w;
+                    }
+                } else {
+                    const float2* rp2 = reinterpret_cast<const float2*>(x + en * N);
+#pragma unroll
+                    for (int q = 0; q < N / 2; ++q) {
+                        const float2 v = rp2[q];
+                        dst[t][2 * q] = v.x; dst[t][2 * q + 1] = v.y;
+                    }
                 }
             } else {
-                const float2* rp2 = reinterpret_cast<const float2*>(x + en * N);
 #pragma unroll
-                for (int q = 0; q < N / 2; ++q) {
-                    const float2 v = rp2[q];
-                    dst[2 * q] = v.x; dst[2 * q + 1] = v.y;
-                }
+                for (int k = 0; k < N; ++k) dst[t][k] = p.xf[k];
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) dst[k] = p.xf[k];
         }
     };
 
-    int64_t tile = t_begin + wave;
+    int64_t grp = g_begin + wave;
 #ifdef HJBX_DIAG_CLOCK
     // DIAGNOSTIC BUILD ONLY (tools/diag_clock.py): shader-clock and 100 MHz wall stamps around the tile loop
     const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
 #endif
-    float xs[N];
-    load_row(tile, xs);
-    for (; tile < t_end;) {
-        // the weights are loop invariant: without this barrier LICM hoists hundreds of LDS reads out of the
-        // tile loop into registers and spills them to scratch
+    float xs[TL][N];
+    load_rows(grp, xs);
+    for (; grp < g_end;) {
+        // the weights are loop invariant: without this barrier LICM hoists LDS reads out of the tile loop
         asm volatile("" ::: "memory");
-        const int64_t env = tile * 32 + i;
-        const bool valid = env < B;
-        float e[N], z[N];
-        float ee = 0.f;
+        float e[TL][N], z[TL][N], ee[TL];
 #pragma unroll
-        for (int k = 0; k < N; ++k) e[k] = xs[k] - p.xf[k];
-        sys.wrap(e);
+        for (int t = 0; t < TL; ++t) {
+            ee[t] = 0.f;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            ee += e[k] * e[k];
-            z[k] = (e[k] - p.mean[k]) / p.std[k];
+            for (int k = 0; k < N; ++k) e[t][k] = xs[t][k] - p.xf[k];
+            sys.wrap(e[t]);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                ee[t] += e[t][k] * e[t][k];
+                z[t][k] = (e[t][k] - p.mean[k]) / p.std[k];
+            }
         }
-        // claim the next tile now and fetch its row: the HBM latency hides behind this tile's ~50k cycles of MFMAs
+        // claim the next group now and fetch its rows: the HBM latency hides behind this group's MFMAs
         int nxt = 0;
         if (lane == 0) nxt = atomicAdd(&L.next, 1);
-        const int64_t tile_next = t_begin + __builtin_amdgcn_readfirstlane(nxt);
-        load_row(tile_next, xs);
+        const int64_t grp_next = g_begin + __builtin_amdgcn_readfirstlane(nxt);
+        load_rows(grp_next, xs);
 
-        // All element-wise work (ReLU, mask building, mask application, 2y, |y|^2) is done lazily inside the
-        // B-operand fetch of the NEXT product, so it issues in the shadow of the 64-cycle MFMAs instead of
-        // forming VALU-only phases between the chains.
+        // All element-wise work (ReLU, mask application, 2y, |y|^2) is done inside the B-operand fetch of the NEXT
+        // product, one or two instructions per MFMA group.
+        float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
 
         // ---- layer 1: H1' (128 x 32) = W1' (128 x N) . Z' (N x 32) --------------------------------------
-        f32x16 a1[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a1[fb][r] = 0.f;
-        float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
-        mfma_chain<OffW1F, N / 2, 4, 2>(a1, ring4, w1f, [&](int st) { return h ? z[2 * st + 1] : z[2 * st]; });
+        f32x16 a1[TL][4];
+        zero_acc(a1);
+        mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
 
         // ---- layer 2: H2' (128 x 32) = W2' . relu(H1') ---------------------------------------------------
-        f32x16 a2[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a2[fb][r] = 0.f;
-        mfma_chain<OffW2F, 64, 4, 2>(
-            a2, ring4, w2f, [&](int st) { return relu1(a1[st >> 4][st & 15]); });
+        f32x16 a2[TL][4];
+        zero_acc(a2);
+        mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, w2f, [&](int st, int t) { return relu1(a1[t][st >> 4][st & 15]); });
 
         // ---- layer 3: Y' (64 x 32) = W3' . relu(H2') ------------------------------------------------------
-        f32x16 y[2];
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[ob][r] = 0.f;
-        mfma_chain<OffW3F, 64, 2, 2>(
-            y, ring2, w3f, [&](int st) { return relu1(a2[st >> 4][st & 15]); });
+        f32x16 y[TL][2];
+        zero_acc(y);
+        mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, w3f, [&](int st, int t) { return relu1(a2[t][st >> 4][st & 15]); });
 
-        float vpart = 0.f;
+        float vpart[TL];
+#pragma unroll
+        for (int t = 0; t < TL; ++t) vpart[t] = 0.f;
         if (!gout) {  // value only
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
+            for (int t = 0; t < TL; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) vpart += y[ob][r] * y[ob][r];
-            const float vs = vpart + __shfl_xor(vpart, 32, 64);
-            if (valid && h == 0) Vout[env] = vs + p.eps_s * ee;
-            tile = tile_next;
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vpart[t] += y[t][ob][r] * y[t][ob][r];
+                const float vs = vpart[t] + __shfl_xor(vpart[t], 32, 64);
+                const int64_t env = (grp * TL + t) * 32 + i;
+                if (env < B && h == 0) Vout[env] = vs + p.eps_s * ee[t];
+            }
+            grp = grp_next;
             continue;
         }
 
         // ---- backward 3: dH2' (128 x 32) = W3 (128 x 64) . (2 Y') -------------------------------------------
-        f32x16 d2[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d2[fb][r] = 0.f;
-        mfma_chain<OffW3B, 32, 4, 2>(
-            d2, ring4, w3b, [&](int st) {
-                const float v = y[st >> 4][st & 15];
-                vpart += v * v;
-                return 2.f * v;  // dV/dy
-            });
+        f32x16 d2[TL][4];
+        zero_acc(d2);
+        mfma_chain<OffW3B, 32, 4, 2, TL>(d2, ring4, w3b, [&](int st, int t) {
+            const float v = y[t][st >> 4][st & 15];
+            vpart[t] += v * v;
+            return 2.f * v;  // dV/dy
+        });
 #ifndef HJBX_DIAG_CLOCK
         if (Vout) {
-            const float vs = vpart + __shfl_xor(vpart, 32, 64);
-            if (valid && h == 0) Vout[env] = vs + p.eps_s * ee;
+#pragma unroll
+            for (int t = 0; t < TL; ++t) {
+                const float vs = vpart[t] + __shfl_xor(vpart[t], 32, 64);
+                const int64_t env = (grp * TL + t) * 32 + i;
+                if (env < B && h == 0) Vout[env] = vs + p.eps_s * ee[t];
+            }
         }
 #endif
 
         // ---- backward 2: dH1' (128 x 32) = W2 . (dH2' . [h2 > 0]) -------------------------------------------
         // (the pre-activations a2 are still in registers: compare + select per element, no mask words to build)
-        f32x16 d1[4];
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d1[fb][r] = 0.f;
-        mfma_chain<OffW2B, 64, 4, 2>(
-            d1, ring4, w2b, [&](int st) { return a2[st >> 4][st & 15] > 0.f ? d2[st >> 4][st & 15] : 0.f; });
+        f32x16 d1[TL][4];
+        zero_acc(d1);
+        mfma_chain<OffW2B, 64, 4, 2, TL>(
+            d1, ring4, w2b, [&](int st, int t) { return a2[t][st >> 4][st & 15] > 0.f ? d2[t][st >> 4][st & 15] : 0.f; });
 
         // ---- backward 1: dZ' (N x 32) = W1 (N x 128) . (dH1' . [h1 > 0]) on the VALU ---------------------------
-        // Only N of an MFMA tile's 32 rows would be useful here (7.6 % of all MFMA time for n = 4); instead
-        // each lane dots its 64 resident features with W1' rows (wave-uniform float4 LDS broadcasts), the two
-        // lane halves are added with one cross-half shuffle per row, and the matrix pipe stays free for the
-        // partner wave.
-        // [h1 > 0] is re-derived by recomputing layer 1 (N/2 x 4 MFMAs, 1 % of the tile): cheaper in issue slots
-        // than building and carrying 128 mask bits per lane through the forward pass.
+        // Only N of an MFMA tile's 32 rows would be useful here (7.6 % of all MFMA time for n = 4); instead each
+        // lane dots its 64 resident features with W1' rows (wave-uniform float4 LDS broadcasts) and the two lane
+        // halves are added with one cross-half shuffle per row.  [h1 > 0] is re-derived by recomputing layer 1
+        // (N/2 x 4 MFMAs, 1 % of the tile): cheaper in issue slots than carrying 128 mask bits per lane.
+        zero_acc(a1);
+        mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
+        for (int t = 0; t < TL; ++t) {
+            float part[NP];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[fb][r] = 0.f;
-        mfma_chain<OffW1F, N / 2, 4, 2>(a1, ring4, w1f, [&](int st) { return h ? z[2 * st + 1] : z[2 * st]; });
-        float part[NP];
+            for (int k = 0; k < NP; ++k) part[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) part[k] = 0.f;
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+                for (int s = 0; s < 16; ++s) {
+                    const float dv = a1[t][kb][s] > 0.f ? d1[t][kb][s] : 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float dv = a1[kb][s] > 0.f ? d1[kb][s] : 0.f;
+                    for (int q = 0; q < NP / 4; ++q) {
+                        const float4 w = w1t[(32 * kb + perm(s)) * (NP / 4) + q];
+                        part[4 * q + 0] += w.x * dv;
+                        part[4 * q + 1] += w.y * dv;
+                        part[4 * q + 2] += w.z * dv;
+                        part[4 * q + 3] += w.w * dv;
+                    }
+                }
+            float g[N];
 #pragma unroll
-                for (int q = 0; q < NP / 4; ++q) {
-                    const float4 w = w1t[(32 * kb + perm(s)) * (NP / 4) + q];
-                    part[4 * q + 0] += w.x * dv;
-                    part[4 * q + 1] += w.y * dv;
-                    part[4 * q + 2] += w.z * dv;
-                    part[4 * q + 3] += w.w * dv;
+            for (int k = 0; k < N; ++k) {
+                const float v = part[k] + __shfl_xor(part[k], 32, 64);
+                g[k] = v / p.std[k] + 2.f * p.eps_s * e[t][k];
+            }
+            const int64_t env = (grp * TL + t) * 32 + i;
+            if (env < B && h == 0) {
+                if constexpr ((N * 4) % 16 == 0) {
+                    float4* op = reinterpret_cast<float4*>(gout + env * N);
+#pragma unroll
+                    for (int q = 0; q < N / 4; ++q) op[q] = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+                } else {
+                    float2* op = reinterpret_cast<float2*>(gout + env * N);
+#pragma unroll
+                    for (int q = 0; q < N / 2; ++q) op[q] = make_float2(g[2 * q], g[2 * q + 1]);
                 }
             }
-        float g[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const float v = part[k] + __shfl_xor(part[k], 32, 64);
-            g[k] = v / p.std[k] + 2.f * p.eps_s * e[k];
         }
-        if (valid && h == 0) {
-            if constexpr ((N * 4) % 16 == 0) {
-                float4* op = reinterpret_cast<float4*>(gout + env * N);
-#pragma unroll
-                for (int q = 0; q < N / 4; ++q) op[q] = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-            } else {
-                float2* op = reinterpret_cast<float2*>(gout + env * N);
-#pragma unroll
-                for (int q = 0; q < N / 2; ++q) op[q] = make_float2(g[2 * q], g[2 * q + 1]);
-            }
-        }
-        tile = tile_next;
+        grp = grp_next;
     }
 #ifdef HJBX_DIAG_CLOCK
     {
         const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1r = __builtin_amdgcn_s_memrealtime();
-        // the caller of the diagnostic build passes a scratch "V" buffer of >= 4*gridDim.x*kWaves floats and gradV != NULL
+        // the caller of the diagnostic build passes a scratch "V" buffer of >= 4*gridDim.x*WAVES floats and gradV != NULL
         if (Vout && gout && lane == 0) {
-            float* d = Vout + 4 * ((int64_t)blockIdx.x * kWaves + wave);
+            float* d = Vout + 4 * ((int64_t)blockIdx.x * WAVES + wave);
             d[0] = (float)(t1c - t0c); d[1] = (float)(t1r - t0r);
             d[2] = (float)(t0r - tentry); d[3] = (float)(tentry & 0xFFFFFFull);
         }
@@ -368,10 +373,11 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void k_value_grad_mfma(S sys,
 
 template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* st) {
     constexpr int N = S::N;
+    constexpr int TL = HJBX_MLP_TL, WAVES = HJBX_MLP_WAVES;
     MlpP<N> p;
     for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.std[k] = (float)mlp->std[k]; p.xf[k] = (float)mlp->xf[k]; }
     p.eps_s = (float)mlp->eps_scalar;
-    const int64_t ntiles = (B + 31) / 32;
+    const int64_t ngroups = (B + 32 * TL - 1) / (32 * TL);
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -380,10 +386,10 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
             return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_grad_f32: no HIP device");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    int64_t grid = (ntiles + kWaves - 1) / kWaves;
-    if (grid > n_cu) grid = n_cu;  // one resident workgroup per CU (104 KB of LDS each), waves stride over tiles
-    hipLaunchKernelGGL((k_value_grad_mfma<S>), dim3((unsigned)grid), dim3(kThreads), 0, (hipStream_t)st, sys, p,
-                       (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ntiles);
+    int64_t grid = (ngroups + WAVES - 1) / WAVES;
+    if (grid > n_cu) grid = n_cu;  // one resident workgroup per CU (106 KB of LDS each)
+    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
+                       (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_grad_f32: %s", hipGetErrorString(e));
     return HJBX_OK;

@@ -44,7 +44,7 @@ for k in range(96):
 e1.record()
 torch.cuda.synchronize()
 print(f"event-timed value_grad + vhjb_step pair: {e0.elapsed_time(e1)/96*1e3:.1f} us per pair")
-NW = int(os.environ.get('NW', '8'))
+NW = int(os.environ.get("NW", "8"))
 st = V[: 4 * 256 * NW].view(-1, 4).cpu()
 cyc, rt = st[:, 0].double(), st[:, 1].double()
 ok = rt > 0
@@ -55,4 +55,4 @@ fill, start = st[:, 2].double(), st[:, 3].double()
 print(f"LDS fill (entry -> loop start): median {fill.median()/100:.1f} us, max {fill.max()/100:.1f} us; "
       f"kernel-entry skew across waves: {(start.max()-start.min())/100:.1f} us; last wave end - first entry: "
       f"{((start+fill+rt).max()-start.min())/100:.1f} us")
-print(f"MFMA cycles per wave = {128//NW} tiles x 776 x 64; pipe share per SIMD = {128/4*776*64/cyc[ok].median():.3f}")
+print(f"MFMA cycles per wave = 128 tiles per CU x 784 MFMAs x 64 cycles; pipe share per SIMD = {128/4*784*64/cyc[ok].median():.3f}")
