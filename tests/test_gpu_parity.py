@@ -422,3 +422,40 @@ def test_full_size_properties_cartpole():
     idx = torch.arange(0, B, 4099, device="cuda")
     want = O.simulate(orc_system("cartpole"), x[idx].cpu().numpy().astype(np.float64), np.zeros((idx.numel(), 1)))
     check(a[idx], want, 1e-5, 3.0, angle_idx=[1])
+
+
+@pytest.mark.parametrize("name,B,T", [("acrobot", 1 << 20, 40), ("quad2d", 1 << 18, 60), ("nearhover", 1 << 18, 40)])
+def test_full_size_closed_loops(name, B, T):
+    """BASELINE configs[2] (acrobot energy shaping, B = 2^20) and configs[3] (Quadrotors2D hover, B = 2^18) at full
+    size through size-independent properties, plus an oracle check on a strided sample."""
+    d, c = _ctrl_objects(name)
+    cfg = make_vhjb_config(name)
+    n, m = d.get_dimension()
+    task = _abi.make_task(n, m, cfg.Q, cfg.R, np.eye(n), c.xf, getattr(c, "uf", cfg.uf), cfg.obs_min, cfg.obs_max, cfg.epsilon)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    x0 = d.get_initial_state(B, generator=gen)
+    desc = c._descriptor()
+    a = _ops.rollout_feedback(d.system, desc, x0, T, task=task, terminate=True, log_traj=True, log_u=False, log_cost=True)
+    b = _ops.rollout_feedback(d.system, desc, x0, T, task=task, terminate=True, log_traj=False)
+    assert torch.equal(a["done_step"], b["done_step"]) and torch.equal(a["x_final"], b["x_final"])      # logging changes nothing
+    assert torch.equal(a["total_cost"], b["total_cost"])
+    ds = a["done_step"].long()
+    assert int(ds.min()) >= 0 and int(ds.max()) <= T
+    # the state is held after termination; the final state equals the log at the terminal index
+    idx = ds.clamp(max=T)
+    gathered = a["traj"][idx, torch.arange(B, device="cuda")]
+    assert torch.equal(gathered, a["x_final"])
+    # per-step costs add up to total_cost (f32 summation order differs: loose tolerance), zero after termination
+    tot = a["cost"].double().sum(0)
+    assert torch.allclose(tot, a["total_cost"].double(), rtol=1e-4, atol=1e-4)
+    after = torch.arange(T + 1, device="cuda")[:, None] > ds[None, :]
+    assert float(a["cost"][after].abs().max()) == 0.0
+    # oracle on a strided sample, short prefix (the closed loops amplify fp32 rounding with t)
+    sel = torch.arange(0, B, B // 509, device="cuda")
+    ref = O.rollout_feedback(orc_system(name), desc, x0[sel].cpu().numpy().astype(np.float64), T, task=task, terminate=True)
+    gs, ws = a["done_step"][sel].cpu().numpy(), ref["done_step"]
+    keep = gs == ws
+    assert keep.mean() > 0.97
+    mbf = 0.02 if name in ("acrobot", "cartpole") else 0.0
+    check(a["traj"][:10, sel][:, torch.as_tensor(keep)], ref["traj"][:10, keep], 5e-4, np.abs(ref["traj"][:10]).max(), angle_idx=ANGLE_IDX[name],
+          max_bad_frac=mbf)

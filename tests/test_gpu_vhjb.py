@@ -244,3 +244,60 @@ def test_sgdr_schedule_values():
     assert abs(sgdr_schedule(1500, **kw) - 5e-6) < 1e-12
     assert abs(sgdr_schedule(2000, **kw)) < 1e-18 and abs(sgdr_schedule(2500, **kw) - 5e-6) < 1e-18
     assert sgdr_schedule(20000, **kw) < 1e-18 and sgdr_schedule(10 ** 6, **kw) < 1e-18
+
+
+def test_full_size_nearhover_vhjb_rollout():
+    """BASELINE configs[4]: 10-D quadcopter, VHJB controller (fused MFMA value gradient + fused step with the RK4
+    integrator and the HJB residual by-product), B = 2^20: oracle check on a strided sample + invariants."""
+    d, ctl = controller("nearhover", torch.float32)
+    d.integrator = _abi.RK4
+    ctl.value_function_approximator.load_quadratic(ctl.P, noise=0.02, generator=torch.Generator(device="cuda").manual_seed(9))
+    B, T = 1 << 20, 6
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x0 = d.get_initial_state(B, generator=gen) * 0.5
+    out = ctl.rollout_batch(x0, max_steps=T, log_residual=True)
+    ds = out["done_step"].long()
+    assert int(ds.min()) >= 0 and int(ds.max()) == T
+    dn = out["done"]
+    assert torch.equal(dn.sum(0), torch.ones(B, device="cuda")) and torch.equal(dn.argmax(0), ds)
+    # V = e'Pe (+2 % noise): the normalised residual along live steps is small for the embedded LQR value function
+    live = torch.arange(T + 1, device="cuda")[:, None] < ds[None, :]
+    assert float(out["residual"][live].abs().median()) < 0.2 and float(out["residual"][~live].abs().max()) == 0.0
+    sel = torch.arange(0, B, B // 300, device="cuda")
+    mlp, W = oracle_mlp(ctl)
+    ref = O.vhjb_rollout(O.System.from_dynamics(d), ctl._task, mlp, *W, x0[sel].cpu().numpy().astype(np.float64), T, integrator=_abi.RK4)
+    keep = out["done_step"][sel].cpu().numpy() == ref["done_step"]
+    assert keep.mean() > 0.97
+    tr = out["traj"][:, sel].cpu().numpy().astype(np.float64)
+    err = np.abs(wrapped_diff(tr, ref["traj"], ANGLE_IDX["nearhover"]))[:, keep]
+    assert err.max() < 1e-3, err.max()
+
+
+def test_evaluation_harness_lockstep():
+    """scripts.test_vhjb_policy.test_policy: learned vs model-based closed loops from the same starts.
+    With the LQR value function embedded the learned quadrotor policy must track the hover LQR closely."""
+    from q_learning_with_hjb_amd.scripts.test_vhjb_policy import load_systems, test_policy
+    dyn, pol, mb = load_systems("quadrotors2DHovering")
+    pol.value_function_approximator.load_quadratic(pol.P)
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(-0.3, 0.3, (16, 6))
+    res = test_policy(pol, dyn, mb, T=3.0, x0=x0)
+    S = res["t_span"].shape[0]
+    assert res["xs_learned"].shape == (S, 16, 6) and res["us_model_based"].shape == (S - 1, 16, 2)
+    assert np.allclose(res["xs_learned"][0], res["xs_model_based"][0])
+    # same start, nearly the same law (V = e'(P + eps I)e; the learned law uses the true f2(x), the LQR its
+    # linearisation B): trajectories and accumulated costs agree closely
+    assert np.abs(res["xs_learned"] - res["xs_model_based"]).max() < 0.15
+    cl, cm = res["cost_learned"].sum(0), res["cost_model_based"].sum(0)
+    assert np.all(np.abs(cl - cm) < 0.05 * cm + 1e-3)
+    # and both regulate to the hover point
+    assert np.abs(res["xs_learned"][-1]).max() < 0.1
+
+
+def test_cli_main_smoke(capsys):
+    from q_learning_with_hjb_amd.scripts.test_vhjb_policy import main
+    lists, res = main(["--env_name", "lqr", "--epochs", "3", "--eval_batch", "4", "--T", "1"])
+    out = capsys.readouterr().out.strip().splitlines()[-1]
+    import json
+    s = json.loads(out)
+    assert s["env"] == "lqr" and s["epochs"] == 3 and len(lists) == 6 and res["xs_learned"].shape[1] == 4
