@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1 << 20, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-mlp", action="store_true", help="value gradient through PyTorch matmuls instead of the fused kernel")
+    ap.add_argument("--stepwise", action="store_true", help="two launches per step (value_grad + vhjb_step) instead of the persistent rollout kernel")
     ap.add_argument("--cpu-sample-envs", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
     return ap.parse_args()
 
@@ -76,33 +77,106 @@ def main():
     x0 = dyn.get_initial_state(B, generator=gen)
 
     n, m = dyn.get_dimension()
-    RING = 64                                    # time-major log ring: (RING, B, n) states + costs + done flags
-    traj = torch.empty((RING, B, n), device="cuda")
-    cost = torch.empty((RING, B), device="cuda")
-    done = torch.empty((RING, B), device="cuda")
-    done_step = torch.full((B,), -1, dtype=torch.int32, device="cuda")
-    traj[0].copy_(x0)
     sysh, task = dyn.system, ctl._task
     T_max = 1 << 30                              # no forced termination inside the timed region
-
-    def step(t):
-        s, d = t % RING, (t + 1) % RING
-        g = ctl.get_v_gradient(traj[s])
-        _ops.vhjb_step(sysh, task, t, T_max, traj[s], g, traj[d], cost[s], done[s], done_step)
+    flops_per_env = 4.0 * (n * 128 + 128 * 128 + 128 * 64)          # value net fwd + input-grad MACs x 2
+    step_bytes_per_env = 4.0 * (3 * n + 2)                          # step kernel: read x, gradV; write x', cost, done
+    done_step = torch.full((B,), -1, dtype=torch.int32, device="cuda")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for t in range(W):
-        step(t)
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        step(t)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    fused = ctl.fused_value_grad and not args.stepwise
+    kernel_ms = {}
+    if fused:
+        # ---- the whole closed loop in persistent launches of <= CHUNK steps (hjbx_vhjb_rollout_f32) ----------------
+        CHUNK = 256
+        desc = vf.descriptor()
+        x_cur = x0
+        t = 0
+
+        def run(nsteps, events=None):
+            nonlocal x_cur, t
+            left = nsteps
+            while left > 0:
+                k = min(CHUNK, left)
+                if events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                out = _ops.vhjb_rollout(sysh, task, desc, x_cur, k, T_max, done_step, t_first=t, log_traj=True, want_x_out=True)
+                if events is not None:
+                    e1.record()
+                    events.append((e0, e1, k))
+                x_cur = out["x_out"]
+                t += k
+                left -= k
+            return out
+
+        run(W)
+        barrier()
+        evs = []
+        t0 = time.perf_counter()
+        run(K, evs)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launch_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)
+        steps_per_launch = sum(k for _, _, k in evs) / len(evs)
+        kernel_ms["k_vhjb_rollout_mfma"] = launch_ms
+        roofline = dict(bound="mfma", kernel="k_vhjb_rollout_mfma (hjbx_vhjb_rollout_f32)",
+                        achieved=flops_per_env * B * steps_per_launch / (launch_ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        traffic=None, avg_launch_ms=launch_ms, steps_per_launch=steps_per_launch)
+    else:
+        # ---- one value-gradient launch + one step launch per environment step ---------------------------------------
+        RING = 64                                    # time-major log ring: (RING, B, n) states + costs + done flags
+        traj = torch.empty((RING, B, n), device="cuda")
+        cost = torch.empty((RING, B), device="cuda")
+        done = torch.empty((RING, B), device="cuda")
+        traj[0].copy_(x0)
+
+        def step(t):
+            s_, d_ = t % RING, (t + 1) % RING
+            g = ctl.get_v_gradient(traj[s_])
+            _ops.vhjb_step(sysh, task, t, T_max, traj[s_], g, traj[d_], cost[s_], done[s_], done_step)
+
+        for t in range(W):
+            step(t)
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(W, W + K):
+            step(t)
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # per-kernel launch durations: one event pair brackets a run of back-to-back launches of ONE kernel (an event
+        # per launch would put the event's own queue packet into every measurement)
+        def timed_run(fn, reps=100, warm=20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for r in range(warm):
+                fn(r)
+            e0.record()
+            for r in range(reps):
+                fn(warm + r)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        t_base = W + K
+        g_hold = [ctl.get_v_gradient(traj[t_base % RING])]
+        vg_ms = timed_run(lambda r: g_hold.__setitem__(0, ctl.get_v_gradient(traj[(t_base + r) % RING])))
+        ds_scratch = torch.full((B,), -1, dtype=torch.int32, device="cuda")   # keeps the real done_step untouched
+        st_ms = timed_run(lambda r: _ops.vhjb_step(sysh, task, t_base + r, T_max, traj[(t_base + r) % RING], g_hold[0],
+                                                    traj[(t_base + r + 1) % RING], cost[(t_base + r) % RING], done[(t_base + r) % RING],
+                                                    ds_scratch))
+        kernel_ms = dict(value_grad=vg_ms, k_vhjb_step=st_ms, k_vhjb_step_GBs=step_bytes_per_env * B / (st_ms * 1e-3) / 1e9)
+        if ctl.fused_value_grad:
+            roofline = dict(bound="mfma", kernel="k_value_grad_mfma (hjbx_value_grad_f32)", achieved=flops_per_env * B / (vg_ms * 1e-3) / 1e12,
+                            peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", traffic=None, avg_launch_ms=vg_ms)
+        else:
+            roofline = dict(bound="hbm", kernel="k_vhjb_step (hjbx_vhjb_step_f32)", achieved=step_bytes_per_env * B / (st_ms * 1e-3) / 1e9,
+                            peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, avg_launch_ms=st_ms)
+
     if dist is not None:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -116,51 +190,20 @@ def main():
     live = int(live.item())
     value = live / elapsed
 
-    # ---- per-kernel launch durations with HIP events on the launch stream (separate pass over the same slabs) ----
-    # One event pair brackets a run of back-to-back launches of ONE kernel (an event per launch would put the
-    # event's own queue packet into every measurement); rocprofv3 per-kernel averages under profiles/ agree.
-    def timed_run(fn, reps=100, warm=20):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for r in range(warm):                      # no idle gap between warm-up and the measured launches
-            fn(r)
-        e0.record()
-        for r in range(reps):
-            fn(warm + r)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    t_base = W + K
-    g_hold = [ctl.get_v_gradient(traj[t_base % RING])]
-    vg_ms = timed_run(lambda r: g_hold.__setitem__(0, ctl.get_v_gradient(traj[(t_base + r) % RING])))
-    ds_scratch = torch.full((B,), -1, dtype=torch.int32, device="cuda")   # keeps the real done_step untouched
-    st_ms = timed_run(lambda r: _ops.vhjb_step(sysh, task, t_base + r, T_max, traj[(t_base + r) % RING], g_hold[0],
-                                                traj[(t_base + r + 1) % RING], cost[(t_base + r) % RING], done[(t_base + r) % RING],
-                                                ds_scratch))
-    flops_per_env = 4.0 * (n * 128 + 128 * 128 + 128 * 64)          # fwd + input-grad MACs x 2
-    step_bytes_per_env = 4.0 * (3 * n + 2)                          # read x, gradV; write x', cost, done
-    if ctl.fused_value_grad:
-        roofline = dict(bound="mfma", kernel="k_value_grad_mfma (hjbx_value_grad_f32)", achieved=flops_per_env * B / (vg_ms * 1e-3) / 1e12,
-                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", traffic=None)
-    else:
-        roofline = dict(bound="hbm", kernel="k_vhjb_step (hjbx_vhjb_step_f32)", achieved=step_bytes_per_env * B / (st_ms * 1e-3) / 1e9,
-                        peak=HBM_PEAK_GBS, unit="GB/s", traffic=None)
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    roofline["avg_launch_ms"] = vg_ms if ctl.fused_value_grad else st_ms
     tfile = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if collected
     if os.path.exists(tfile):
         with open(tfile) as f:
             roofline["traffic"] = json.load(f).get(roofline["kernel"].split(" ")[0])
-    other = dict(value_grad_ms=vg_ms, vhjb_step_ms=st_ms,
-                 vhjb_step_hbm_GBs=step_bytes_per_env * B / (st_ms * 1e-3) / 1e9,
-                 value_grad_TFLOPs=flops_per_env * B / (vg_ms * 1e-3) / 1e12)
+    other = kernel_ms
 
     out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20", value=value, unit="env-steps/s", n_gpus=world,
                steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                data="synthetic",
                config=dict(workload="cartpole balancing + vhjb controller (BASELINE configs[1])", batch_per_gpu=B, global_batch=B * world,
                            state_dim=n, control_dim=m, integrator="euler", mlp="4-128-128-64 relu, no bias",
-                           value_grad="fused HIP MFMA kernel" if ctl.fused_value_grad else "PyTorch-ROCm matmuls",
+                           value_grad=("persistent fused rollout kernel (MFMA value net + step)" if fused else
+                                       "fused HIP MFMA kernel + step kernel" if ctl.fused_value_grad else "PyTorch-ROCm matmuls + step kernel"),
                            live_fraction=live / (B * world * K), parallelism=f"env-shard x{world}, no data-path collective"),
                roofline=roofline, kernels=other)
 

@@ -212,6 +212,18 @@ HJBX_DECLARE(double, f64)
 int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V,
                         float* gradV, int64_t B, void* stream);
 
+/* rollout_trajectory (vhjb.py:171-193) for B environments, `n_steps` consecutive iterations t = t_first ..
+ * t_first+n_steps-1 of its loop in ONE launch: per step the value gradient (as hjbx_value_grad_f32, weights staged
+ * in LDS once per launch) followed by exactly hjbx_vhjb_step_f32's per-environment code; the state stays in
+ * registers between steps.  Bit-identical to calling those two entry points n_steps times.
+ *   x (B,n): states at step t_first.            done_step (B,) int32 in/out (-1 = live), as hjbx_vhjb_step.
+ *   traj (n_steps+1,B,n) or NULL: slab k = state at step t_first+k (slab 0 = x).     x_out (B,n) or NULL: final state.
+ *   cost, done (n_steps,B): the tuples emitted at each step.   resid (n_steps,B) or NULL.   u_log (n_steps,B,m) or NULL.
+ * A whole reference rollout is t_first = 0, n_steps = T_max + 1 (the last iteration emits the forced terminal tuple). */
+int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
+                          int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
+                          float* resid, int32_t* done_step, float* x_out, int64_t B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
 _SOURCES = ("hjbx_kernels.hip", "hjbx_mlp.hip")
-_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", os.path.join("..", "..", "include", "hjbx.h"))
+_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 
 
 class HjbxTask(C.Structure):
@@ -167,7 +167,7 @@ def _typed_signatures():
 
 EXPORTED_SYMBOLS = (
     ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
-     "hjbx_reduce_workspace_bytes", "hjbx_value_grad_f32"]
+     "hjbx_reduce_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32"]
     + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
 )
 
@@ -198,6 +198,8 @@ def lib() -> C.CDLL:
         L.hjbx_dims.argtypes = [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.hjbx_value_grad_f32.restype = C.c_int
         L.hjbx_value_grad_f32.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _VP]
+        L.hjbx_vhjb_rollout_f32.restype = C.c_int
+        L.hjbx_vhjb_rollout_f32.argtypes = [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")

@@ -216,3 +216,23 @@ def value_grad(sys, mlp_desc, x, want_v=True, want_grad=True):
     g = torch.empty_like(x) if want_grad else None
     check(lib().hjbx_value_grad_f32(sys.ptr, ref(mlp_desc), _p(x), _p(V), _p(g), B, _stream()))
     return V, g
+
+
+def vhjb_rollout(sys, task, mlp_desc, x, n_steps, T_max, done_step, t_first=0, integrator=_abi.EULER, log_traj=True, log_u=False,
+                 log_residual=False, want_x_out=False):
+    """`n_steps` closed-loop VHJB steps (value gradient + step) in ONE kernel launch (f32).  `done_step` (B,) int32 is
+    updated in place.  Returns a dict of time-major device tensors: traj (n_steps+1,B,n) | None, cost, done
+    (n_steps,B), u (n_steps,B,m) | None, residual (n_steps,B) | None, x_out (B,n) | None."""
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n), torch.float32)
+    _chk(done_step, "done_step", (B,), torch.int32)
+    dev = x.device
+    traj = torch.empty((n_steps + 1, B, sys.n), dtype=torch.float32, device=dev) if log_traj else None
+    ulog = torch.empty((n_steps, B, sys.m), dtype=torch.float32, device=dev) if log_u else None
+    cost = torch.empty((n_steps, B), dtype=torch.float32, device=dev)
+    done = torch.empty((n_steps, B), dtype=torch.float32, device=dev)
+    resid = torch.empty((n_steps, B), dtype=torch.float32, device=dev) if log_residual else None
+    x_out = torch.empty_like(x) if want_x_out else None
+    check(lib().hjbx_vhjb_rollout_f32(sys.ptr, ref(task), ref(mlp_desc), int(integrator), int(t_first), int(n_steps), int(T_max), _p(x),
+                                      _p(traj), _p(ulog), _p(cost), _p(done), _p(resid), _p(done_step), _p(x_out), B, _stream()))
+    return dict(traj=traj, u=ulog, cost=cost, done=done, residual=resid, x_out=x_out)

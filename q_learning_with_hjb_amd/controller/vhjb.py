@@ -360,6 +360,13 @@ class VHJBController(Controller):
         x0 = x0.to(dtype=self.dtype, device=self.device).contiguous()
         B, n = x0.shape
         sysh, task, integ = self.dynamics.system, self._task, self.dynamics.integrator
+        if self.fused_value_grad and self.dtype == torch.float32:
+            # the whole loop (T live steps + the forced terminal iteration) in one persistent kernel launch
+            done_step = torch.full((B,), -1, dtype=torch.int32, device=self.device)
+            out = _ops.vhjb_rollout(sysh, task, self.value_function_approximator.descriptor(), x0, T + 1, T, done_step, integrator=integ,
+                                    log_traj=True, log_u=log_u, log_residual=log_residual)
+            return dict(traj=out["traj"][:T + 1], cost=out["cost"], done=out["done"], done_step=done_step,
+                        u=None if out["u"] is None else out["u"][:T], residual=out["residual"])
         traj = torch.empty((T + 2, B, n), dtype=self.dtype, device=self.device)  # slot T+1 is scratch for the last call
         cost = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)
         done = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)

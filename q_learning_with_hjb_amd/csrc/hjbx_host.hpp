@@ -1,0 +1,72 @@
+// hjbx_host.hpp -- host-side conversion of the ABI descriptors (doubles) into the by-value kernel argument PODs and
+// the handle -> concrete device system dispatch.  Shared by hjbx_kernels.hip and hjbx_mlp.hip; not part of the ABI.
+#pragma once
+#include <cstring>
+
+#include "hjbx_internal.hpp"
+#include "hjbx_systems.hpp"
+
+using namespace hjbx;
+
+template <typename T, int M> inline Limits<T, M> make_limits(const hjbx_system* s) {
+    Limits<T, M> l;
+    for (int j = 0; j < M; ++j) { l.umin[j] = (T)s->umin[j]; l.umax[j] = (T)s->umax[j]; }
+    l.dt = (T)s->dt;
+    return l;
+}
+
+template <typename T, int N, int M> inline TaskP<T, N, M> make_task(const hjbx_task* t) {
+    TaskP<T, N, M> k;
+    memset(&k, 0, sizeof(k));
+    if (!t) return k;
+    for (int i = 0; i < N * N; ++i) { k.Q[i] = (T)t->Q[i]; k.P[i] = (T)t->P[i]; }
+    for (int i = 0; i < M * M; ++i) { k.R[i] = (T)t->R[i]; k.Rinv[i] = (T)t->Rinv[i]; }
+    for (int i = 0; i < N; ++i) { k.xf[i] = (T)t->xf[i]; k.omin[i] = (T)t->obs_min[i]; k.omax[i] = (T)t->obs_max[i]; }
+    for (int j = 0; j < M; ++j) k.uf[j] = (T)t->uf[j];
+    k.eps = (T)t->eps;
+    return k;
+}
+
+template <typename T, int N, int M> inline CtrlP<T, N, M> make_ctrl(const hjbx_controller* c) {
+    CtrlP<T, N, M> k;
+    memset(&k, 0, sizeof(k));
+    k.wrap_error = c->wrap_error;
+    for (int i = 0; i < M * N; ++i) k.K[i] = (T)c->K[i];
+    for (int i = 0; i < N; ++i) k.xf[i] = (T)c->xf[i];
+    for (int j = 0; j < M; ++j) k.uf[j] = (T)c->uf[j];
+    for (int i = 0; i < N * N; ++i) k.P[i] = (T)c->P[i];
+    for (int i = 0; i < 3; ++i) k.Kes[i] = (T)c->Kes[i];
+    k.eps_energy = (T)c->eps_energy;
+    k.eps_state = (T)c->eps_state;
+    k.eps_region = (T)c->eps_region;
+    return k;
+}
+
+template <typename T, int N, int M> inline Linear<T, N, M> make_linear(const hjbx_system* s) {
+    Linear<T, N, M> l;
+    for (int i = 0; i < N * N; ++i) l.A[i] = (T)s->p[i];
+    for (int i = 0; i < N * M; ++i) l.Bm[i] = (T)s->p[N * N + i];
+    return l;
+}
+
+// Calls f(system_pod) with the concrete device system type for this handle; false if unsupported.
+template <typename T, typename F> inline bool with_system(const hjbx_system* s, F&& f) {
+    switch (s->kind) {
+    case HJBX_SYS_LINEAR:
+        if (s->n == 2 && s->m == 1) { f(make_linear<T, 2, 1>(s)); return true; }
+        if (s->n == 2 && s->m == 2) { f(make_linear<T, 2, 2>(s)); return true; }
+        if (s->n == 4 && s->m == 1) { f(make_linear<T, 4, 1>(s)); return true; }
+        if (s->n == 4 && s->m == 2) { f(make_linear<T, 4, 2>(s)); return true; }
+        if (s->n == 6 && s->m == 2) { f(make_linear<T, 6, 2>(s)); return true; }
+        return false;
+    case HJBX_SYS_CARTPOLE: { Cartpole<T> c{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(c); return true; }
+    case HJBX_SYS_ACROBOT: {
+        Acrobot<T> a{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3], (T)s->p[4], (T)s->p[5], (T)s->p[6]};
+        f(a); return true;
+    }
+    case HJBX_SYS_QUAD2D: { Quad2D<T> q{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(q); return true; }
+    case HJBX_SYS_NEARHOVER: { NearHover<T> q{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(q); return true; }
+    }
+    return false;
+}
+

@@ -14,6 +14,7 @@
 
 #include "hjbx_internal.hpp"
 #include "hjbx_systems.hpp"
+#include "hjbx_host.hpp"
 
 using namespace hjbx;
 
@@ -344,39 +345,11 @@ __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M
     T xs[N], gs[N], xo[N], u[M];
     RowIO<T, N>::load(x, i, xs);
     RowIO<T, N>::load(g, i, gs);
-    const int32_t ds = done_step[i];
-#pragma unroll
-    for (int k = 0; k < N; ++k) xo[k] = xs[k];
-#pragma unroll
-    for (int j = 0; j < M; ++j) u[j] = T(0);
-    T c = T(0), d = T(0), res = T(0);
-    if (ds < 0) {
-        T e[N];
-        error_coords(sys, tk.xf, xs, e);
-        if (t >= T_max || out_of_box<S, T>(tk, e)) {  // vhjb.py:176-181 and 188-191
-            c = quad_form<N>(tk.P, e);
-            d = T(1);
-            done_step[i] = t;
-        } else {  // vhjb.py:183-186
-            T f1[N], f2[N * M], ur[M];
-            sys.affine(xs, f1, f2);
-            control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
-            const T l = running_cost_e<S, T>(tk, e, u);
-            c = l * lim.dt;
-            if (resid_t) {  // vhjb.py:231-233: gradV . (f1 + f2 u) / (l + eps) + 1
-                T vdot = T(0);
-#pragma unroll
-                for (int r = 0; r < N; ++r) {
-                    T a = T(0);
-#pragma unroll
-                    for (int j = 0; j < M; ++j) a += f2[r * M + j] * u[j];
-                    vdot += gs[r] * (f1[r] + a);
-                }
-                res = vdot / (l + tk.eps) + T(1);
-            }
-            integrate<INTEG>(sys, lim.dt, xs, u, xo);
-        }
-    }
+    int32_t ds = done_step[i];
+    const int32_t ds_in = ds;
+    T c, d, res;
+    vhjb_step_env<INTEG>(sys, tk, lim, t, T_max, resid_t != nullptr, xs, gs, ds, xo, u, c, d, res);
+    if (ds != ds_in) done_step[i] = ds;
     RowIO<T, N>::store(xn, i, xo);
     if (u_out) RowIO<T, M>::store(u_out, i, u);
     cost_t[i] = c;
@@ -431,70 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_feedback(S sys, TaskP<T, S::
     if (x_final) RowIO<T, N>::store(x_final, i, x);
 }
 
-// ----------------------------------------------------------------------------------------------
-// host side: descriptor conversion and dispatch
-// ----------------------------------------------------------------------------------------------
-template <typename T, int M> static Limits<T, M> make_limits(const hjbx_system* s) {
-    Limits<T, M> l;
-    for (int j = 0; j < M; ++j) { l.umin[j] = (T)s->umin[j]; l.umax[j] = (T)s->umax[j]; }
-    l.dt = (T)s->dt;
-    return l;
-}
-
-template <typename T, int N, int M> static TaskP<T, N, M> make_task(const hjbx_task* t) {
-    TaskP<T, N, M> k;
-    memset(&k, 0, sizeof(k));
-    if (!t) return k;
-    for (int i = 0; i < N * N; ++i) { k.Q[i] = (T)t->Q[i]; k.P[i] = (T)t->P[i]; }
-    for (int i = 0; i < M * M; ++i) { k.R[i] = (T)t->R[i]; k.Rinv[i] = (T)t->Rinv[i]; }
-    for (int i = 0; i < N; ++i) { k.xf[i] = (T)t->xf[i]; k.omin[i] = (T)t->obs_min[i]; k.omax[i] = (T)t->obs_max[i]; }
-    for (int j = 0; j < M; ++j) k.uf[j] = (T)t->uf[j];
-    k.eps = (T)t->eps;
-    return k;
-}
-
-template <typename T, int N, int M> static CtrlP<T, N, M> make_ctrl(const hjbx_controller* c) {
-    CtrlP<T, N, M> k;
-    memset(&k, 0, sizeof(k));
-    k.wrap_error = c->wrap_error;
-    for (int i = 0; i < M * N; ++i) k.K[i] = (T)c->K[i];
-    for (int i = 0; i < N; ++i) k.xf[i] = (T)c->xf[i];
-    for (int j = 0; j < M; ++j) k.uf[j] = (T)c->uf[j];
-    for (int i = 0; i < N * N; ++i) k.P[i] = (T)c->P[i];
-    for (int i = 0; i < 3; ++i) k.Kes[i] = (T)c->Kes[i];
-    k.eps_energy = (T)c->eps_energy;
-    k.eps_state = (T)c->eps_state;
-    k.eps_region = (T)c->eps_region;
-    return k;
-}
-
-template <typename T, int N, int M> static Linear<T, N, M> make_linear(const hjbx_system* s) {
-    Linear<T, N, M> l;
-    for (int i = 0; i < N * N; ++i) l.A[i] = (T)s->p[i];
-    for (int i = 0; i < N * M; ++i) l.Bm[i] = (T)s->p[N * N + i];
-    return l;
-}
-
-// Calls f(system_pod) with the concrete device system type for this handle; false if unsupported.
-template <typename T, typename F> static bool with_system(const hjbx_system* s, F&& f) {
-    switch (s->kind) {
-    case HJBX_SYS_LINEAR:
-        if (s->n == 2 && s->m == 1) { f(make_linear<T, 2, 1>(s)); return true; }
-        if (s->n == 2 && s->m == 2) { f(make_linear<T, 2, 2>(s)); return true; }
-        if (s->n == 4 && s->m == 1) { f(make_linear<T, 4, 1>(s)); return true; }
-        if (s->n == 4 && s->m == 2) { f(make_linear<T, 4, 2>(s)); return true; }
-        if (s->n == 6 && s->m == 2) { f(make_linear<T, 6, 2>(s)); return true; }
-        return false;
-    case HJBX_SYS_CARTPOLE: { Cartpole<T> c{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(c); return true; }
-    case HJBX_SYS_ACROBOT: {
-        Acrobot<T> a{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3], (T)s->p[4], (T)s->p[5], (T)s->p[6]};
-        f(a); return true;
-    }
-    case HJBX_SYS_QUAD2D: { Quad2D<T> q{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(q); return true; }
-    case HJBX_SYS_NEARHOVER: { NearHover<T> q{(T)s->p[0], (T)s->p[1], (T)s->p[2], (T)s->p[3]}; f(q); return true; }
-    }
-    return false;
-}
+// host side: descriptor conversion and dispatch live in hjbx_host.hpp (shared with hjbx_mlp.hip)
 
 static int unsupported(const hjbx_system* s) {
     return hjbx_set_error(HJBX_EUNSUPPORTED, "no kernel for system kind %d with n=%d m=%d", s->kind, s->n, s->m);

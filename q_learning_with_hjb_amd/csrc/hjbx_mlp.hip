@@ -29,6 +29,7 @@
 
 #include "hjbx_internal.hpp"
 #include "hjbx_systems.hpp"
+#include "hjbx_host.hpp"
 
 using namespace hjbx;
 
@@ -145,22 +146,17 @@ template <int TL, int NOUT> __device__ __forceinline__ void zero_acc(f32x16 (&a)
             for (int r = 0; r < 16; ++r) a[t][o][r] = 0.f;
 }
 
-template <typename S, int TL, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
-                                                                         const float* __restrict__ W2g, const float* __restrict__ W3g,
-                                                                         const float* __restrict__ x, float* __restrict__ Vout,
-                                                                         float* __restrict__ gout, int64_t B, int64_t ngroups) {
-    constexpr int N = S::N;
-    constexpr int THREADS = WAVES * 64;
-    static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
-    constexpr int NP = MlpLds<N>::NP;
-    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+// lane-dependent LDS operand bases of one wave; everything else is a compile-time offset
+struct MlpCtx {
+    uint32_t w1f, w2f, w3f, w3b, w2b;
+    const float4* w1t;
+    int i, h;  // i = lane & 31: A-operand row / environment column; h = lane >> 5: k parity / accumulator row-half
+};
 
-    const int tid = threadIdx.x;
-    if (tid == 0) L.next = WAVES;  // groups 0..WAVES-1 of the range are taken statically
-#ifdef HJBX_DIAG_CLOCK
-    const unsigned long long tentry = __builtin_amdgcn_s_memrealtime();
-#endif
+template <int N, int THREADS>
+__device__ __forceinline__ void mlp_fill_lds(MlpLds<N>& L, const float* __restrict__ W1g, const float* __restrict__ W2g,
+                                             const float* __restrict__ W3g, int tid) {
+    constexpr int NP = MlpLds<N>::NP;
     for (int idx = tid; idx < N * kH1; idx += THREADS) L.W1[(idx / kH1) * kLD1 + (idx % kH1)] = W1g[idx];
     for (int idx = tid; idx < kH1 * NP; idx += THREADS) {
         const int f = idx / NP, k = idx % NP;
@@ -168,21 +164,183 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
     }
     for (int idx = tid; idx < kH1 * kH2; idx += THREADS) L.W2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
     for (int idx = tid; idx < kH2 * kH3; idx += THREADS) L.W3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
-    __syncthreads();
+}
 
-    const int lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31;  // A-operand row / environment column
-    const int h = lane >> 5;  // k parity / accumulator row-half
-
-    // lane-dependent LDS bases; everything else is a compile-time offset
+template <int N> __device__ __forceinline__ MlpCtx mlp_ctx(MlpLds<N>& L, int lane) {
+    constexpr int NP = MlpLds<N>::NP;
+    MlpCtx c;
+    c.i = lane & 31;
+    c.h = lane >> 5;
     // (the low 32 bits of a flat pointer into the LDS aperture are the LDS byte address)
     const uint32_t lds0 = (uint32_t)(uintptr_t)&L;
-    const uint32_t w1f = lds0 + (uint32_t)offsetof(MlpLds<N>, W1) + 4u * (h * kLD1 + i);      // forward:  W1[2s + h][32 fb + i]
-    const uint32_t w2f = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (4 * h * kLD2 + i);  //           W2[32 kb + perm(s) + 4h][32 fb + i]
-    const uint32_t w3f = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (4 * h * kLD3 + i);  //           W3[32 kb + perm(s) + 4h][32 ob + i]
-    const uint32_t w3b = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (i * kLD3 + 4 * h);  // backward: W3[32 fb + i][32 kb + perm(s) + 4h]
-    const uint32_t w2b = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (i * kLD2 + 4 * h);  //           W2[32 fb + i][32 kb + perm(s) + 4h]
-    const float4* w1t = reinterpret_cast<const float4*>(L.W1T + 4 * h * NP);                  // W1'[32 kb + perm(s) + 4h][0..NP)
+    c.w1f = lds0 + (uint32_t)offsetof(MlpLds<N>, W1) + 4u * (c.h * kLD1 + c.i);      // forward:  W1[2s + h][32 fb + i]
+    c.w2f = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (4 * c.h * kLD2 + c.i);  //           W2[32 kb + perm(s) + 4h][32 fb + i]
+    c.w3f = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (4 * c.h * kLD3 + c.i);  //           W3[32 kb + perm(s) + 4h][32 ob + i]
+    c.w3b = lds0 + (uint32_t)offsetof(MlpLds<N>, W3) + 4u * (c.i * kLD3 + 4 * c.h);  // backward: W3[32 fb + i][32 kb + perm(s) + 4h]
+    c.w2b = lds0 + (uint32_t)offsetof(MlpLds<N>, W2) + 4u * (c.i * kLD2 + 4 * c.h);  //           W2[32 fb + i][32 kb + perm(s) + 4h]
+    c.w1t = reinterpret_cast<const float4*>(L.W1T + 4 * c.h * NP);                   // W1'[32 kb + perm(s) + 4h][0..NP)
+    return c;
+}
+
+// V and dV/dx of the TL tiles whose state rows are in xs (one environment per lane, identical in both lane
+// halves).  On return every lane holds its environment's V and (if want_grad) gradient.
+template <typename S, int TL>
+__device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p, const MlpCtx& c, const float (&xs)[TL][S::N],
+                                               bool want_grad, float (&V)[TL], float (&g)[TL][S::N]) {
+    constexpr int N = S::N;
+    constexpr int NP = MlpLds<N>::NP;
+    const int h = c.h;
+    float e[TL][N], z[TL][N], ee[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+        ee[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) e[t][k] = xs[t][k] - p.xf[k];
+        sys.wrap(e[t]);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            ee[t] += e[t][k] * e[t][k];
+            z[t][k] = (e[t][k] - p.mean[k]) / p.std[k];
+        }
+    }
+    // All element-wise work (ReLU, mask application, 2y, |y|^2) is done inside the B-operand fetch of the NEXT
+    // product, one or two instructions per MFMA group.
+    float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
+
+    // ---- layer 1: H1' (128 x 32) = W1' (128 x N) . Z' (N x 32) --------------------------------------
+    f32x16 a1[TL][4];
+    zero_acc(a1);
+    mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, c.w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
+
+    // ---- layer 2: H2' (128 x 32) = W2' . relu(H1') ---------------------------------------------------
+    f32x16 a2[TL][4];
+    zero_acc(a2);
+    mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, c.w2f, [&](int st, int t) { return relu1(a1[t][st >> 4][st & 15]); });
+
+    // ---- layer 3: Y' (64 x 32) = W3' . relu(H2') ------------------------------------------------------
+    f32x16 y[TL][2];
+    zero_acc(y);
+    mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, c.w3f, [&](int st, int t) { return relu1(a2[t][st >> 4][st & 15]); });
+
+    float vpart[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) vpart[t] = 0.f;
+    if (!want_grad) {  // value only
+#pragma unroll
+        for (int t = 0; t < TL; ++t) {
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vpart[t] += y[t][ob][r] * y[t][ob][r];
+            V[t] = vpart[t] + __shfl_xor(vpart[t], 32, 64) + p.eps_s * ee[t];
+        }
+        return;
+    }
+
+    // ---- backward 3: dH2' (128 x 32) = W3 (128 x 64) . (2 Y') -------------------------------------------
+    f32x16 d2[TL][4];
+    zero_acc(d2);
+    mfma_chain<OffW3B, 32, 4, 2, TL>(d2, ring4, c.w3b, [&](int st, int t) {
+        const float v = y[t][st >> 4][st & 15];
+        vpart[t] += v * v;
+        return 2.f * v;  // dV/dy
+    });
+#pragma unroll
+    for (int t = 0; t < TL; ++t) V[t] = vpart[t] + __shfl_xor(vpart[t], 32, 64) + p.eps_s * ee[t];
+
+    // ---- backward 2: dH1' (128 x 32) = W2 . (dH2' . [h2 > 0]) -------------------------------------------
+    // (the pre-activations a2 are still in registers: compare + select per element, no mask words to build)
+    f32x16 d1[TL][4];
+    zero_acc(d1);
+    mfma_chain<OffW2B, 64, 4, 2, TL>(
+        d1, ring4, c.w2b, [&](int st, int t) { return a2[t][st >> 4][st & 15] > 0.f ? d2[t][st >> 4][st & 15] : 0.f; });
+
+    // ---- backward 1: dZ' (N x 32) = W1 (N x 128) . (dH1' . [h1 > 0]) on the VALU ---------------------------
+    // Only N of an MFMA tile's 32 rows would be useful here (7.6 % of all MFMA time for n = 4); instead each
+    // lane dots its 64 resident features with W1' rows (wave-uniform float4 LDS broadcasts) and the two lane
+    // halves are added with one cross-half shuffle per row.  [h1 > 0] is re-derived by recomputing layer 1
+    // (N/2 x 4 MFMAs, 1 % of the tile): cheaper in issue slots than carrying 128 mask bits per lane.
+    zero_acc(a1);
+    mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, c.w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+        float part[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) part[k] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float dv = a1[t][kb][s] > 0.f ? d1[t][kb][s] : 0.f;
+#pragma unroll
+                for (int q = 0; q < NP / 4; ++q) {
+                    const float4 w = c.w1t[(32 * kb + perm(s)) * (NP / 4) + q];
+                    part[4 * q + 0] += w.x * dv;
+                    part[4 * q + 1] += w.y * dv;
+                    part[4 * q + 2] += w.z * dv;
+                    part[4 * q + 3] += w.w * dv;
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float v = part[k] + __shfl_xor(part[k], 32, 64);
+            g[t][k] = v / p.std[k] + 2.f * p.eps_s * e[t][k];
+        }
+    }
+}
+
+template <int N> __device__ __forceinline__ void load_row(const float* __restrict__ x, int64_t env, float (&dst)[N]) {
+    if constexpr ((N * 4) % 16 == 0) {
+        const float4* rp = reinterpret_cast<const float4*>(x + env * N);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 v = rp[q];
+            dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        }
+    } else {
+        const float2* rp2 = reinterpret_cast<const float2*>(x + env * N);
+#pragma unroll
+        for (int q = 0; q < N / 2; ++q) {
+            const float2 v = rp2[q];
+            dst[2 * q] = v.x; dst[2 * q + 1] = v.y;
+        }
+    }
+}
+
+template <int N> __device__ __forceinline__ void store_row(float* __restrict__ out, int64_t env, const float (&src)[N]) {
+    if constexpr ((N * 4) % 16 == 0) {
+        float4* op = reinterpret_cast<float4*>(out + env * N);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) op[q] = make_float4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+    } else if constexpr ((N * 4) % 8 == 0) {
+        float2* op = reinterpret_cast<float2*>(out + env * N);
+#pragma unroll
+        for (int q = 0; q < N / 2; ++q) op[q] = make_float2(src[2 * q], src[2 * q + 1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) out[env * N + q] = src[q];
+    }
+}
+
+// ---- kernel 1: V and dV/dx for a batch of states (hjbx_value_grad_f32) ---------------------------------------
+template <typename S, int TL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
+                                                                         const float* __restrict__ W2g, const float* __restrict__ W3g,
+                                                                         const float* __restrict__ x, float* __restrict__ Vout,
+                                                                         float* __restrict__ gout, int64_t B, int64_t ngroups) {
+    constexpr int N = S::N;
+    static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
+    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    const int tid = threadIdx.x;
+    if (tid == 0) L.next = WAVES;  // groups 0..WAVES-1 of the range are taken statically
+#ifdef HJBX_DIAG_CLOCK
+    const unsigned long long tentry = __builtin_amdgcn_s_memrealtime();
+#endif
+    mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const MlpCtx c = mlp_ctx<N>(L, lane);
+    const int i = c.i, h = c.h;
 
     // Work distribution: the workgroup owns a contiguous range of tile groups and its waves pull the next one
     // from an LDS counter.  (With a static stride the older wave of each SIMD pair wins the matrix-pipe
@@ -197,21 +355,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
         for (int t = 0; t < TL; ++t) {
             const int64_t en = (grp * TL + t) * 32 + i;
             if (grp < g_end && en < B) {
-                if constexpr ((N * 4) % 16 == 0) {
-                    const float4* rp = reinterpret_cast<const float4*>(x + en * N);
-#pragma unroll
-                    for (int q = 0; q < N / 4; ++q) {
-                        const float4 v = rp[q];
-                        dst[t][4 * q] = v.x; dst[t][4 * q + 1] = v.y; dst[t][4 * q + 2] = v.z; dst[t][4 * q + 3] = v.w;
-                    }
-                } else {
-                    const float2* rp2 = reinterpret_cast<const float2*>(x + en * N);
-#pragma unroll
-                    for (int q = 0; q < N / 2; ++q) {
-                        const float2 v = rp2[q];
-                        dst[t][2 * q] = v.x; dst[t][2 * q + 1] = v.y;
-                    }
-                }
+                load_row<N>(x, en, dst[t]);
             } else {
 #pragma unroll
                 for (int k = 0; k < N; ++k) dst[t][k] = p.xf[k];
@@ -224,137 +368,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
     // DIAGNOSTIC BUILD ONLY (tools/diag_clock.py): shader-clock and 100 MHz wall stamps around the tile loop
     const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
 #endif
-    float xs[TL][N];
+    float xs[TL][N], xn[TL][N];
     load_rows(grp, xs);
     for (; grp < g_end;) {
         // the weights are loop invariant: without this barrier LICM hoists LDS reads out of the tile loop
         asm volatile("" ::: "memory");
-        float e[TL][N], z[TL][N], ee[TL];
-#pragma unroll
-        for (int t = 0; t < TL; ++t) {
-            ee[t] = 0.f;
-#pragma unroll
-            for (int k = 0; k < N; ++k) e[t][k] = xs[t][k] - p.xf[k];
-            sys.wrap(e[t]);
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                ee[t] += e[t][k] * e[t][k];
-                z[t][k] = (e[t][k] - p.mean[k]) / p.std[k];
-            }
-        }
         // claim the next group now and fetch its rows: the HBM latency hides behind this group's MFMAs
         int nxt = 0;
         if (lane == 0) nxt = atomicAdd(&L.next, 1);
         const int64_t grp_next = g_begin + __builtin_amdgcn_readfirstlane(nxt);
-        load_rows(grp_next, xs);
+        load_rows(grp_next, xn);
 
-        // All element-wise work (ReLU, mask application, 2y, |y|^2) is done inside the B-operand fetch of the NEXT
-        // product, one or two instructions per MFMA group.
-        float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
-
-        // ---- layer 1: H1' (128 x 32) = W1' (128 x N) . Z' (N x 32) --------------------------------------
-        f32x16 a1[TL][4];
-        zero_acc(a1);
-        mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
-
-        // ---- layer 2: H2' (128 x 32) = W2' . relu(H1') ---------------------------------------------------
-        f32x16 a2[TL][4];
-        zero_acc(a2);
-        mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, w2f, [&](int st, int t) { return relu1(a1[t][st >> 4][st & 15]); });
-
-        // ---- layer 3: Y' (64 x 32) = W3' . relu(H2') ------------------------------------------------------
-        f32x16 y[TL][2];
-        zero_acc(y);
-        mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, w3f, [&](int st, int t) { return relu1(a2[t][st >> 4][st & 15]); });
-
-        float vpart[TL];
-#pragma unroll
-        for (int t = 0; t < TL; ++t) vpart[t] = 0.f;
-        if (!gout) {  // value only
-#pragma unroll
-            for (int t = 0; t < TL; ++t) {
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) vpart[t] += y[t][ob][r] * y[t][ob][r];
-                const float vs = vpart[t] + __shfl_xor(vpart[t], 32, 64);
-                const int64_t env = (grp * TL + t) * 32 + i;
-                if (env < B && h == 0) Vout[env] = vs + p.eps_s * ee[t];
-            }
-            grp = grp_next;
-            continue;
-        }
-
-        // ---- backward 3: dH2' (128 x 32) = W3 (128 x 64) . (2 Y') -------------------------------------------
-        f32x16 d2[TL][4];
-        zero_acc(d2);
-        mfma_chain<OffW3B, 32, 4, 2, TL>(d2, ring4, w3b, [&](int st, int t) {
-            const float v = y[t][st >> 4][st & 15];
-            vpart[t] += v * v;
-            return 2.f * v;  // dV/dy
-        });
-#ifndef HJBX_DIAG_CLOCK
-        if (Vout) {
-#pragma unroll
-            for (int t = 0; t < TL; ++t) {
-                const float vs = vpart[t] + __shfl_xor(vpart[t], 32, 64);
-                const int64_t env = (grp * TL + t) * 32 + i;
-                if (env < B && h == 0) Vout[env] = vs + p.eps_s * ee[t];
-            }
-        }
-#endif
-
-        // ---- backward 2: dH1' (128 x 32) = W2 . (dH2' . [h2 > 0]) -------------------------------------------
-        // (the pre-activations a2 are still in registers: compare + select per element, no mask words to build)
-        f32x16 d1[TL][4];
-        zero_acc(d1);
-        mfma_chain<OffW2B, 64, 4, 2, TL>(
-            d1, ring4, w2b, [&](int st, int t) { return a2[t][st >> 4][st & 15] > 0.f ? d2[t][st >> 4][st & 15] : 0.f; });
-
-        // ---- backward 1: dZ' (N x 32) = W1 (N x 128) . (dH1' . [h1 > 0]) on the VALU ---------------------------
-        // Only N of an MFMA tile's 32 rows would be useful here (7.6 % of all MFMA time for n = 4); instead each
-        // lane dots its 64 resident features with W1' rows (wave-uniform float4 LDS broadcasts) and the two lane
-        // halves are added with one cross-half shuffle per row.  [h1 > 0] is re-derived by recomputing layer 1
-        // (N/2 x 4 MFMAs, 1 % of the tile): cheaper in issue slots than carrying 128 mask bits per lane.
-        zero_acc(a1);
-        mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
+        float V[TL], g[TL][N];
+        mlp_value_grad<S, TL>(sys, p, c, xs, gout != nullptr, V, g);
 #pragma unroll
         for (int t = 0; t < TL; ++t) {
-            float part[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) part[k] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float dv = a1[t][kb][s] > 0.f ? d1[t][kb][s] : 0.f;
-#pragma unroll
-                    for (int q = 0; q < NP / 4; ++q) {
-                        const float4 w = w1t[(32 * kb + perm(s)) * (NP / 4) + q];
-                        part[4 * q + 0] += w.x * dv;
-                        part[4 * q + 1] += w.y * dv;
-                        part[4 * q + 2] += w.z * dv;
-                        part[4 * q + 3] += w.w * dv;
-                    }
-                }
-            float g[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const float v = part[k] + __shfl_xor(part[k], 32, 64);
-                g[k] = v / p.std[k] + 2.f * p.eps_s * e[t][k];
-            }
             const int64_t env = (grp * TL + t) * 32 + i;
             if (env < B && h == 0) {
-                if constexpr ((N * 4) % 16 == 0) {
-                    float4* op = reinterpret_cast<float4*>(gout + env * N);
-#pragma unroll
-                    for (int q = 0; q < N / 4; ++q) op[q] = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-                } else {
-                    float2* op = reinterpret_cast<float2*>(gout + env * N);
-#pragma unroll
-                    for (int q = 0; q < N / 2; ++q) op[q] = make_float2(g[2 * q], g[2 * q + 1]);
-                }
+#ifndef HJBX_DIAG_CLOCK
+                if (Vout) Vout[env] = V[t];
+#endif
+                if (gout) store_row<N>(gout, env, g[t]);
             }
+#pragma unroll
+            for (int k = 0; k < N; ++k) xs[t][k] = xn[t][k];
         }
         grp = grp_next;
     }
@@ -369,6 +406,82 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
         }
     }
 #endif
+}
+
+// ---- kernel 2: the whole VHJB closed loop for n_steps steps in one launch (hjbx_vhjb_rollout_f32) ----------------
+// Per environment tile: state in registers; per step: value gradient on the matrix cores (above), then exactly the
+// per-environment code of hjbx_vhjb_step (vhjb_step_env: bounds / termination, control from gradV, cost, HJB
+// residual, Euler or RK4 step), then the time-major log slabs.  Tiles are independent, so a wave runs all steps of
+// one tile group before pulling the next; the weights are staged into LDS once per launch instead of once per step.
+template <int N, int M> struct RolloutOut {
+    float* traj;   // (n_steps+1, B, N) or NULL: slab k = state at step t_first + k
+    float* u_log;  // (n_steps, B, M) or NULL
+    float* cost;   // (n_steps, B)
+    float* done;   // (n_steps, B)
+    float* resid;  // (n_steps, B) or NULL
+    int32_t* done_step;  // (B) in/out
+    float* x_out;  // (B, N) or NULL
+};
+
+template <int INTEG, typename S, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys, MlpP<S::N> p, TaskP<float, S::N, S::M> tk,
+                                                                           Limits<float, S::M> lim, const float* __restrict__ W1g,
+                                                                           const float* __restrict__ W2g, const float* __restrict__ W3g,
+                                                                           int t_first, int n_steps, int T_max, const float* __restrict__ x,
+                                                                           RolloutOut<S::N, S::M> o, int64_t B, int64_t ngroups) {
+    constexpr int N = S::N, M = S::M;
+    static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
+    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    const int tid = threadIdx.x;
+    if (tid == 0) L.next = WAVES;
+    mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const MlpCtx c = mlp_ctx<N>(L, lane);
+    const int i = c.i, h = c.h;
+    const int64_t groups_per_wg = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int64_t g_begin = (int64_t)blockIdx.x * groups_per_wg;
+    const int64_t g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
+
+    for (int64_t grp = g_begin + wave; grp < g_end;) {
+        const int64_t env = grp * 32 + i;
+        const bool valid = env < B;
+        const bool writer = valid && h == 0;  // both lane halves carry the same environment; half 0 stores
+        float xs[1][N];
+        int32_t ds = 0;                        // padding lanes are "done": they hold xf and emit nothing
+        if (valid) {
+            load_row<N>(x, env, xs[0]);
+            ds = o.done_step[env];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) xs[0][k] = p.xf[k];
+        }
+        if (o.traj && writer) store_row<N>(o.traj, env, xs[0]);
+        for (int k = 0; k < n_steps; ++k) {
+            asm volatile("" ::: "memory");
+            float V[1], g[1][N];
+            mlp_value_grad<S, 1>(sys, p, c, xs, true, V, g);
+            float xo[N], u[M], cst, dn, res;
+            vhjb_step_env<INTEG>(sys, tk, lim, t_first + k, T_max, o.resid != nullptr, xs[0], g[0], ds, xo, u, cst, dn, res);
+            if (writer) {
+                const int64_t row = (int64_t)k * B + env;
+                o.cost[row] = cst;
+                o.done[row] = dn;
+                if (o.resid) o.resid[row] = res;
+                if (o.u_log) store_row<M>(o.u_log + (int64_t)k * B * M, env, u);
+                if (o.traj) store_row<N>(o.traj + (int64_t)(k + 1) * B * N, env, xo);
+            }
+#pragma unroll
+            for (int q = 0; q < N; ++q) xs[0][q] = xo[q];
+        }
+        if (writer) {
+            o.done_step[env] = ds;
+            if (o.x_out) store_row<N>(o.x_out, env, xs[0]);
+        }
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&L.next, 1);
+        grp = g_begin + __builtin_amdgcn_readfirstlane(nxt);
+    }
 }
 
 template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* st) {
@@ -425,4 +538,72 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
     case HJBX_SYS_NEARHOVER: { NearHover<float> q{}; return launch_value_grad(q, mlp, x, V, g, B, stream); }
     }
     return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: no kernel for system kind %d with n=%d", sys->kind, sys->n);
+}
+
+template <typename S>
+static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
+                               int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done, float* resid,
+                               int32_t* done_step, float* x_out, int64_t B, void* st) {
+    constexpr int N = S::N, M = S::M;
+    constexpr int WAVES = HJBX_MLP_WAVES;
+    MlpP<N> p;
+    for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.std[k] = (float)mlp->std[k]; p.xf[k] = (float)mlp->xf[k]; }
+    p.eps_s = (float)mlp->eps_scalar;
+    const auto tk = make_task<float, N, M>(task);
+    const auto lim = make_limits<float, M>(sysh);
+    RolloutOut<N, M> o{traj, u_log, cost, done, resid, done_step, x_out};
+    const int64_t ngroups = (B + 31) / 32;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return hjbx_set_error(HJBX_ENODEVICE, "hjbx_vhjb_rollout_f32: no HIP device");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int64_t grid = (ngroups + WAVES - 1) / WAVES;
+    if (grid > n_cu) grid = n_cu;
+    const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
+    if (integrator == HJBX_EULER)
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
+                           W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
+    else
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<1, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
+                           W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_vhjb_rollout_f32: %s", hipGetErrorString(e));
+    return HJBX_OK;
+}
+
+extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
+                                     int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
+                                     float* resid, int32_t* done_step, float* x_out, int64_t B, void* stream) {
+    if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: NULL system, task or mlp descriptor");
+    if (B < 0 || n_steps < 0 || t_first < 0 || T_max < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: negative size or step index");
+    if (integrator != HJBX_EULER && integrator != HJBX_RK4) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: unknown integrator %d", integrator);
+    if (B == 0) return HJBX_OK;
+    if (!x || !cost || !done || !done_step || !mlp->W1 || !mlp->W2 || !mlp->W3)
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: x, cost, done, done_step and the weights must be non-NULL");
+    if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2,
+                              mlp->h3);
+    const size_t row = (size_t)sys->n * sizeof(float);
+    const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
+    const size_t urow = (size_t)sys->m * sizeof(float);
+    const uintptr_t um = (urow % 16 == 0) ? 15u : (urow % 8 == 0) ? 7u : 3u;
+    if ((reinterpret_cast<uintptr_t>(x) & am) || (traj && (reinterpret_cast<uintptr_t>(traj) & am)) ||
+        (x_out && (reinterpret_cast<uintptr_t>(x_out) & am)) || (u_log && (reinterpret_cast<uintptr_t>(u_log) & um)))
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: x / traj / x_out / u_log must be aligned to their row vector width");
+    for (int k = 0; k < sys->n; ++k)
+        if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: normalization_std[%d] is zero", k);
+    int rc = HJBX_EUNSUPPORTED;
+    const bool ok = with_system<float>(sys, [&](auto S) {
+        using SS = decltype(S);
+        if constexpr (SS::N % 2 == 0)
+            rc = launch_vhjb_rollout<SS>(sys, S, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step,
+                                         x_out, B, stream);
+    });
+    if (!ok || rc == HJBX_EUNSUPPORTED)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
+    return rc;
 }

@@ -322,6 +322,49 @@ template <typename S, typename T> HJBX_DEV bool out_of_box(const TaskP<T, S::N, 
     return out;
 }
 
+// One iteration of rollout_trajectory's loop (reference vhjb.py:175-191) for ONE environment, given dV/dx at its
+// state: shared by the per-step kernel (hjbx_vhjb_step) and the fused whole-rollout kernel (hjbx_vhjb_rollout), so
+// the two produce identical bits.  ds < 0 = live.  A live env outside the observation box (or t >= T_max) emits the
+// terminal tuple (c = e'Pe, d = 1, ds = t) and holds; otherwise u from gradV, c = l dt, d = 0, xo = simulate(x, u),
+// res = gradV.xdot/(l+eps) + 1 (vhjb.py:233, signed) when want_res.  Dead envs emit zeros and hold.
+template <int INTEG, typename S, typename T>
+HJBX_DEV void vhjb_step_env(const S& sys, const TaskP<T, S::N, S::M>& tk, const Limits<T, S::M>& lim, int t, int T_max, bool want_res,
+                            const T* xs, const T* gs, int32_t& ds, T* xo, T* u, T& c, T& d, T& res) {
+    constexpr int N = S::N, M = S::M;
+#pragma unroll
+    for (int k = 0; k < N; ++k) xo[k] = xs[k];
+#pragma unroll
+    for (int j = 0; j < M; ++j) u[j] = T(0);
+    c = T(0); d = T(0); res = T(0);
+    if (ds < 0) {
+        T e[N];
+        error_coords(sys, tk.xf, xs, e);
+        if (t >= T_max || out_of_box<S, T>(tk, e)) {  // vhjb.py:176-181 and 188-191
+            c = quad_form<N>(tk.P, e);
+            d = T(1);
+            ds = t;
+        } else {  // vhjb.py:183-186
+            T f1[N], f2[N * M], ur[M];
+            sys.affine(xs, f1, f2);
+            control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
+            const T l = running_cost_e<S, T>(tk, e, u);
+            c = l * lim.dt;
+            if (want_res) {  // vhjb.py:231-233: gradV . (f1 + f2 u) / (l + eps) + 1
+                T vdot = T(0);
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    T a = T(0);
+#pragma unroll
+                    for (int j = 0; j < M; ++j) a += f2[r * M + j] * u[j];
+                    vdot += gs[r] * (f1[r] + a);
+                }
+                res = vdot / (l + tk.eps) + T(1);
+            }
+            integrate<INTEG>(sys, lim.dt, xs, u, xo);
+        }
+    }
+}
+
 // ---- closed-form controllers -----------------------------------------------------------
 // CK = 0 linear feedback (lqr.py:25-26; quadrotors_model_based_controller.py:36-38, 73-75)
 // CK = 1 cartpole energy shaping (cartpole_energy_shaping.py:65-110), CK = 2 acrobot (acrobot_energy_shaping.py:74-121)

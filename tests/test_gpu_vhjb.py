@@ -135,6 +135,41 @@ def test_rollout_batch_vs_oracle(name, prec):
     assert np.array_equal(dn.sum(0), np.ones(B)) and np.array_equal(dn.argmax(0), ds)
 
 
+@pytest.mark.parametrize("integ", [_abi.EULER, _abi.RK4])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_fused_rollout_kernel_bitwise_equals_stepwise(name, integ):
+    """hjbx_vhjb_rollout_f32 (all steps in one persistent launch, state in registers) produces exactly the bits of
+    hjbx_value_grad_f32 + hjbx_vhjb_step_f32 called step by step; splitting the horizon over two launches changes
+    nothing either."""
+    d, ctl = controller(name, torch.float32)
+    d.integrator = integ
+    ctl.value_function_approximator.load_quadratic(ctl.P, noise=0.05, generator=torch.Generator(device="cuda").manual_seed(3))
+    B, T = 1000, 12                                           # ragged: 1000 = 31 tiles + 8 environments
+    x0 = states_near_target(d, ctl, B, 8, 1.03)
+    n, m = d.get_dimension()
+    vf = ctl.value_function_approximator
+    # step by step
+    traj = torch.empty((T + 2, B, n), device="cuda"); cost = torch.empty((T + 1, B), device="cuda"); done = torch.empty_like(cost)
+    res = torch.empty_like(cost); ul = torch.empty((T + 1, B, m), device="cuda")
+    ds = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    traj[0].copy_(x0)
+    for t in range(T + 1):
+        g = vf.fused_value_grad(traj[t], want_v=False)[1]
+        _ops.vhjb_step(d.system, ctl._task, t, T, traj[t], g, traj[t + 1], cost[t], done[t], ds, u_out=ul[t], integrator=integ, resid_t=res[t])
+    # one launch
+    ds1 = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    one = _ops.vhjb_rollout(d.system, ctl._task, vf.descriptor(), x0, T + 1, T, ds1, integrator=integ, log_u=True, log_residual=True,
+                            want_x_out=True)
+    assert torch.equal(ds1, ds) and torch.equal(one["traj"], traj) and torch.equal(one["cost"], cost) and torch.equal(one["done"], done)
+    assert torch.equal(one["u"], ul) and torch.equal(one["residual"], res) and torch.equal(one["x_out"], traj[T + 1])
+    assert 0 < int((ds < T).sum()) < B
+    # two launches (7 + 6 steps), no logs on the first
+    ds2 = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    a = _ops.vhjb_rollout(d.system, ctl._task, vf.descriptor(), x0, 7, T, ds2, integrator=integ, log_traj=False, want_x_out=True)
+    b = _ops.vhjb_rollout(d.system, ctl._task, vf.descriptor(), a["x_out"], T + 1 - 7, T, ds2, t_first=7, integrator=integ)
+    assert torch.equal(ds2, ds) and torch.equal(b["traj"], traj[7:]) and torch.equal(torch.cat([a["cost"], b["cost"]]), cost)
+
+
 def test_rollout_trajectory_reference_shape():
     """The reference-shaped single-trajectory API: list of (x, cost, done), last tuple done = 1."""
     d, ctl = controller("cartpole")
