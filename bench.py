@@ -191,10 +191,16 @@ def main():
     value = live / elapsed
 
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")           # PMC-derived HBM bytes per launch, if collected
+    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction);
+    # the persistent kernel's traffic is recorded per environment step and scaled to this run's steps per launch
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         with open(tfile) as f:
-            roofline["traffic"] = json.load(f).get(roofline["kernel"].split(" ")[0])
+            rec = json.load(f).get(roofline["kernel"].split(" ")[0])
+        if isinstance(rec, dict):
+            roofline["traffic"] = rec["bytes_per_env_step"] * B * roofline.get("steps_per_launch", 1)
+        elif rec is not None:
+            roofline["traffic"] = rec * (B / float(1 << 20))
     other = kernel_ms
 
     out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20", value=value, unit="env-steps/s", n_gpus=world,

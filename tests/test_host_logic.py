@@ -242,3 +242,19 @@ def test_data_parallel_reduction_equals_single_process(tmp_path):
     assert abs(hl - float(whl)) < 1e-12 and abs(tl - float(wtl)) < 1e-12
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b.numpy(), rtol=1e-10, atol=1e-13)
+
+
+def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
+    """The MFMA kernels prefetch LDS operands from inline asm and retire them with counted s_waitcnt (guide 5.7):
+    the compiler must not touch a destination register between the asm load and its wait.  Audits the ISA of every
+    instantiation (cross-compiles for gfx950, no GPU needed)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_asm_loads
+    asm = tmp_path / "mlp.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S", "--cuda-device-only",
+                    "-o", str(asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_mlp.hip")], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert audit_asm_loads.audit(str(asm)) == 0
+    text = asm.read_text()
+    assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
