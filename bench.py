@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1 << 20, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--torch-mlp", action="store_true", help="value gradient through PyTorch matmuls instead of the fused kernel")
     ap.add_argument("--stepwise", action="store_true", help="two launches per step (value_grad + vhjb_step) instead of the persistent rollout kernel")
     ap.add_argument("--cpu-sample-envs", type=int, default=0, help="0 = auto (about 10-20 s of CPU work)")
@@ -54,12 +55,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from q_learning_with_hjb_amd import _abi, _ops

@@ -381,8 +381,8 @@ static void FN(controller1)(const orc_system* s, const hjbx_controller* c, const
 static int FN(out_of_box)(const orc_system* s, const hjbx_task* t, const REAL* x) { /* vhjb.py:176-177, strict */
     REAL e[HJBX_MAX_N];
     FN(err1)(s, t->xf, x, e);
-    for (int i = 0; i < s->n; ++i)
-        if (e[i] > (REAL)t->obs_max[i] || e[i] < (REAL)t->obs_min[i]) return 1;
+    for (int i = 0; i < s->n; ++i) /* negated non-strict form: identical for finite e, NaN (diverged env) terminates too */
+        if (!(e[i] <= (REAL)t->obs_max[i]) || !(e[i] >= (REAL)t->obs_min[i])) return 1;
     return 0;
 }
 

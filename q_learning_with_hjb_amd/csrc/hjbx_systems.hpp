@@ -316,9 +316,12 @@ HJBX_DEV T running_cost_e(const TaskP<T, S::N, S::M>& tk, const T* e, const T* u
 }
 
 template <typename S, typename T> HJBX_DEV bool out_of_box(const TaskP<T, S::N, S::M>& tk, const T* e) {
-    bool out = false;  // strict compares, vhjb.py:176-177
+    // vhjb.py:176-177: any(e > obs_max) or any(e < obs_min), strict.  Written as negated non-strict compares so a
+    // NaN error coordinate (a diverged environment, e.g. tan near pi/2 in the near-hover model) also terminates
+    // instead of integrating NaNs for the rest of the horizon; for finite e the two forms are identical.
+    bool out = false;
 #pragma unroll
-    for (int i = 0; i < S::N; ++i) out = out || (e[i] > tk.omax[i]) || (e[i] < tk.omin[i]);
+    for (int i = 0; i < S::N; ++i) out = out || !(e[i] <= tk.omax[i]) || !(e[i] >= tk.omin[i]);
     return out;
 }
 

@@ -459,3 +459,16 @@ def test_full_size_closed_loops(name, B, T):
     mbf = 0.02 if name in ("acrobot", "cartpole") else 0.0
     check(a["traj"][:10, sel][:, torch.as_tensor(keep)], ref["traj"][:10, keep], 5e-4, np.abs(ref["traj"][:10]).max(), angle_idx=ANGLE_IDX[name],
           max_bad_frac=mbf)
+
+
+def test_nan_state_terminates_instead_of_propagating():
+    """A diverged environment (NaN state) is latched as done by the step kernel; its neighbours are unaffected."""
+    d = make_dynamics("nearhover")
+    cfg = make_vhjb_config("nearhover")
+    task = _abi.make_task(10, 3, cfg.Q, cfg.R, np.eye(10), cfg.xf, cfg.uf, cfg.obs_min, cfg.obs_max, cfg.epsilon)
+    x = torch.zeros((8, 10), device="cuda"); x[3, 4] = float("nan")
+    g = torch.zeros_like(x); xn = torch.empty_like(x); c = torch.empty(8, device="cuda"); dn = torch.empty(8, device="cuda")
+    ds = torch.full((8,), -1, dtype=torch.int32, device="cuda")
+    _ops.vhjb_step(d.system, task, 5, 100, x, g, xn, c, dn, ds)
+    assert ds.tolist() == [-1, -1, -1, 5, -1, -1, -1, -1] and dn.tolist() == [0, 0, 0, 1, 0, 0, 0, 0]
+    assert not torch.isnan(xn[[0, 1, 2, 4, 5, 6, 7]]).any()
