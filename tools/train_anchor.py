@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""End-to-end anchor: train the VHJB controller with the stock configuration and compare closed-loop costs with the
+model-based baseline from the same start states, the way the reference's notebooks report them (SURVEY section 6:
+cartpole VHJB 9.1409 vs LQR 9.1410 over 10 s from 10 starts; quadrotor 9.389 vs 9.984).  Not bit-comparable (different
+RNG, Flax init) -- a does-learning-work check.   python tools/train_anchor.py --env cartpole --epochs 100"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from q_learning_with_hjb_amd.scripts.test_vhjb_policy import load_systems, test_policy  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="cartpole")
+    ap.add_argument("--epochs", type=int, default=100)
+    ap.add_argument("--trajectories", type=int, default=20, help="rollouts per epoch (reference: 20)")
+    ap.add_argument("--T", type=float, default=10.0)
+    ap.add_argument("--starts", type=int, default=10)
+    args = ap.parse_args()
+    dyn, pol, mb = load_systems(args.env, epochs=args.epochs, num_of_trajectories_per_epoch=args.trajectories)
+    t0 = time.time()
+    lists = pol.train()
+    train_s = time.time() - t0
+    np.random.seed(123)
+    res = test_policy(pol, dyn, mb, T=args.T, batch=args.starts)
+    cl, cm = res["cost_learned"].sum(0), res["cost_model_based"].sum(0)
+    print(json.dumps(dict(env=args.env, epochs=args.epochs, updates=pol.update_counter, train_seconds=round(train_s, 1),
+                          replay_records=len(pol.replay_buffer), avg_traj_len_first=lists[2][0], avg_traj_len_last=lists[2][-1],
+                          hjb_loss_first=lists[4][0] if lists[4] else None, hjb_loss_last=lists[4][-1] if lists[4] else None,
+                          mean_cost_learned=float(cl.mean()), mean_cost_model_based=float(cm.mean()),
+                          per_start_learned=[round(float(v), 3) for v in cl], per_start_model_based=[round(float(v), 3) for v in cm])))
+
+
+if __name__ == "__main__":
+    main()
