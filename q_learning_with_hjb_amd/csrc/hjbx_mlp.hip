@@ -68,8 +68,8 @@ __device__ __forceinline__ float relu1(float v) {
 // t = 0..TL-1 environment tiles; every A operand is one LDS dword per lane.  hipcc sinks compiler-visible
 // ds_reads down to their MFMAs and re-uses two operand registers (read -> lgkmcnt(0) -> 2 MFMAs), whatever the
 // source order or sched_barrier placement.  So the reads are issued from inline asm DEPTH steps ahead and
-// retired with counted s_waitcnt lgkmcnt(N) statements that name their destination registers (guide 5.7,
-// form ii): LDS returns in order, so "at most N newer operations outstanding" means this step's operands have
+// retired with counted s_waitcnt lgkmcnt(N) statements fenced by sched_barrier (guide 5.7, form iii; the ISA is
+// audited by tools/audit_asm_loads.py): LDS returns in order, so "at most N newer operations outstanding" means this step's operands have
 // landed.  Any LDS / SMEM operation the compiler adds in between only makes the count conservative.
 template <int BYTE_OFF> __device__ __forceinline__ float lds_read_b32(uint32_t addr) {
     static_assert(BYTE_OFF >= 0 && BYTE_OFF < 65536, "ds_read_b32 offset field is 16 bits");
@@ -77,12 +77,14 @@ template <int BYTE_OFF> __device__ __forceinline__ float lds_read_b32(uint32_t a
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(BYTE_OFF));
     return v;
 }
-template <int CNT> __device__ __forceinline__ void lds_wait(float& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(CNT)); }
-template <int CNT> __device__ __forceinline__ void lds_wait(float& a, float& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(CNT));
-}
-template <int CNT> __device__ __forceinline__ void lds_wait(float& a, float& b, float& c, float& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(CNT));
+// Counted wait + scheduling fence (guide 5.7, form iii).  The wait is the compiler-visible builtin rather than an asm
+// statement: hipcc pads an s_nop between ANY inline-asm statement and a following MFMA (it must assume the statement
+// wrote the MFMA's operands with a VALU op), which would cost one more issue slot per MFMA group.
+// s_waitcnt simm16 on gfx9: vmcnt = bits 3:0 + 15:14, expcnt = 6:4, lgkmcnt = 11:8 -> 0xC07F leaves vmcnt/expcnt unwaited.
+template <int CNT> __device__ __forceinline__ void lds_wait() {
+    static_assert(CNT >= 0 && CNT <= 15, "");
+    __builtin_amdgcn_s_waitcnt(0xC07F | (CNT << 8));
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <typename Off, int ST, int NOUT, int O = 0> __device__ __forceinline__ void chain_issue(float (&slot)[NOUT], uint32_t base) {
@@ -92,33 +94,44 @@ template <typename Off, int ST, int NOUT, int O = 0> __device__ __forceinline__ 
     }
 }
 
-template <typename Off, int NSTEPS, int NOUT, int DEPTH, int TL, int ST = 0, typename GetB>
-__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[TL][NOUT], float (&ring)[DEPTH + 1][NOUT], uint32_t base, GetB getB) {
-    static_assert(NOUT == 1 || NOUT == 2 || NOUT == 4, "");
-    static_assert(NOUT * DEPTH <= 15, "lgkmcnt is a 4-bit field");
-    static_assert(DEPTH <= 3, "");
-    if constexpr (ST == 0) {  // prologue: the first DEPTH steps' operands
-        if constexpr (0 < DEPTH && 0 < NSTEPS) chain_issue<Off, 0, NOUT>(ring[0], base);
-        if constexpr (1 < DEPTH && 1 < NSTEPS) chain_issue<Off, 1, NOUT>(ring[1], base);
-        if constexpr (2 < DEPTH && 2 < NSTEPS) chain_issue<Off, 2, NOUT>(ring[2], base);
-    }
+template <typename Off, int NSTEPS, int NOUT, int DEPTH, int TL, int ST, typename GetB>
+__device__ __forceinline__ void mfma_chain_step(f32x16 (&acc)[TL][NOUT], float (&ring)[DEPTH + 1][NOUT], float (&b)[2][TL], uint32_t base,
+                                                GetB getB) {
     if constexpr (ST < NSTEPS) {
+        // order inside a step: asm reads for step ST+DEPTH | B operands of step ST+1 (VALU) | counted wait | MFMAs of
+        // step ST.  Two compiler-visible instructions sit between the last asm statement and the first MFMA, and the
+        // MFMAs' B operands were written a whole step earlier, so hipcc needs no s_nop pad in front of the group.
         if constexpr (ST + DEPTH < NSTEPS) chain_issue<Off, ST + DEPTH, NOUT>(ring[(ST + DEPTH) % (DEPTH + 1)], base);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ST + 1 < NSTEPS) {
+#pragma unroll
+            for (int t = 0; t < TL; ++t) b[(ST + 1) & 1][t] = getB(ST + 1, t);
+        }
         constexpr int ahead = (NSTEPS - 1 - ST < DEPTH ? NSTEPS - 1 - ST : DEPTH) * NOUT;  // reads issued after this step's
         float(&cur)[NOUT] = ring[ST % (DEPTH + 1)];
-        if constexpr (NOUT == 1) lds_wait<ahead>(cur[0]);
-        if constexpr (NOUT == 2) lds_wait<ahead>(cur[0], cur[1]);
-        if constexpr (NOUT == 4) lds_wait<ahead>(cur[0], cur[1], cur[2], cur[3]);
-        float b[TL];
-#pragma unroll
-        for (int t = 0; t < TL; ++t) b[t] = getB(ST, t);
+        lds_wait<ahead>();
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-            for (int t = 0; t < TL; ++t) acc[t][o] = MFMA(cur[o], b[t], acc[t][o]);
+            for (int t = 0; t < TL; ++t) acc[t][o] = MFMA(cur[o], b[ST & 1][t], acc[t][o]);
         __builtin_amdgcn_sched_barrier(0);  // keep this step's MFMAs in front of the next step's reads and wait
-        mfma_chain<Off, NSTEPS, NOUT, DEPTH, TL, ST + 1>(acc, ring, base, getB);
+        mfma_chain_step<Off, NSTEPS, NOUT, DEPTH, TL, ST + 1>(acc, ring, b, base, getB);
     }
+}
+
+template <typename Off, int NSTEPS, int NOUT, int DEPTH, int TL, typename GetB>
+__device__ __forceinline__ void mfma_chain(f32x16 (&acc)[TL][NOUT], float (&ring)[DEPTH + 1][NOUT], uint32_t base, GetB getB) {
+    static_assert(NOUT == 1 || NOUT == 2 || NOUT == 4, "");
+    static_assert(NOUT * DEPTH <= 15, "lgkmcnt is a 4-bit field");
+    static_assert(DEPTH <= 3 && NSTEPS >= 1, "");
+    // prologue: the first DEPTH steps' operands and the first step's B operands
+    if constexpr (0 < DEPTH && 0 < NSTEPS) chain_issue<Off, 0, NOUT>(ring[0], base);
+    if constexpr (1 < DEPTH && 1 < NSTEPS) chain_issue<Off, 1, NOUT>(ring[1], base);
+    if constexpr (2 < DEPTH && 2 < NSTEPS) chain_issue<Off, 2, NOUT>(ring[2], base);
+    float b[2][TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) b[0][t] = getB(0, t);
+    mfma_chain_step<Off, NSTEPS, NOUT, DEPTH, TL, 0>(acc, ring, b, base, getB);
 }
 
 // byte offsets (from the lane-dependent base) of the A operand of (step, output block) for each product

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Audit of the inline-asm LDS prefetch in hjbx_mlp.hip (guide section 5.7, item 1): between an asm `ds_read_b32 vX`
-and the counted asm `s_waitcnt lgkmcnt(N)` that retires it, no compiler-generated instruction may touch vX (a copy
+and the counted `s_waitcnt lgkmcnt(N)` that retires it, no compiler-generated instruction may touch vX (a copy
 or spill there would read the register before the data has landed).  Scans the device assembly of every kernel.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -S --cuda-device-only -o /tmp/mlp.s csrc/hjbx_mlp.hip
@@ -43,13 +43,15 @@ def audit(path):
                 pending.append(int(m.group(1)))
                 nreads += 1
                 continue
-            m = re.match(r"s_waitcnt lgkmcnt\((\d+)\)", s)
-            if m:
-                keep = int(m.group(1))
-                pending = pending[len(pending) - keep:] if keep else []
             continue
         if s.startswith("s_endpgm"):
             pending = []
+            continue
+        if s.startswith("s_waitcnt"):   # the counted waits are the compiler-visible builtin; LDS returns in order
+            m = re.search(r"lgkmcnt\((\d+)\)", s)
+            if m:
+                keep = int(m.group(1))
+                pending = pending[len(pending) - keep:] if keep else []
             continue
         touched = regs_of(s.split(";")[0]) & set(pending)
         if touched:
