@@ -13,7 +13,7 @@ class Cartpole(Dynamics):
         super().__init__(config)
 
     def _system_params(self, config):
-        return np.array([config.mc, config.mp, config.l, config.g], np.float64)
+        return config.system_params()
 
     # Manipulator terms for ONE state -- set-up helpers (linearisation); the batched path never
     # forms them (the kernels use the reduced closed form, csrc/hjbx_systems.hpp).

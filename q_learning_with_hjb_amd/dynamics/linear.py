@@ -18,4 +18,4 @@ class LinearDynamics(Dynamics):
         super().__init__(config)
 
     def _system_params(self, config):
-        return np.concatenate([np.asarray(config.A, np.float64).ravel(), np.asarray(config.B, np.float64).ravel()])
+        return config.system_params()
