@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1 << 20, help="environments per GPU")
+    ap.add_argument("--system", default="cartpole", choices=["cartpole", "quad2d", "nearhover", "linear"],
+                    help="default cartpole = BASELINE configs[1]; quad2d / nearhover = the VHJB loops of configs[3] / configs[4]")
+    ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"], help="euler = the reference's integrator (parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--torch-mlp", action="store_true", help="value gradient through PyTorch matmuls instead of the fused kernel")
@@ -67,19 +70,35 @@ def main():
             dist.init_process_group(backend=args.backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    import q_learning_with_hjb_amd as pkg
+    if local_rank == 0:
+        pkg.build_library()                      # no-op when csrc/libhjbx.so is current (it ships prebuilt)
+    if world > 1:
+        dist.barrier()
     from q_learning_with_hjb_amd import _abi, _ops
     from q_learning_with_hjb_amd.configs import defaults as D
     from q_learning_with_hjb_amd.controller.vhjb import VHJBController
     from q_learning_with_hjb_amd.dynamics.cartpole import Cartpole
+    from q_learning_with_hjb_amd.dynamics.linear import LinearDynamics
+    from q_learning_with_hjb_amd.dynamics.quadrotors import NearHoverQuadcopter, Quadrotors2D
 
     B, K, W = args.batch, args.steps, args.warmup
-    dyn = Cartpole(D.cartpole_dynamics_config())
-    ctl = VHJBController(dyn, D.cartpole_vhjb_config(), fused_value_grad=not args.torch_mlp)
+    dyn, ccfg, label = {
+        "cartpole": lambda: (Cartpole(D.cartpole_dynamics_config()), D.cartpole_vhjb_config(), "cartpole balancing + vhjb controller (BASELINE configs[1])"),
+        "quad2d": lambda: (Quadrotors2D(D.quadrotors2d_dynamics_config()), D.quadrotors2d_vhjb_config(), "Quadrotors2D hovering + vhjb controller (BASELINE configs[3])"),
+        "nearhover": lambda: (NearHoverQuadcopter(D.near_hover_dynamics_config()), D.near_hover_vhjb_config(), "10-D near-hover quadcopter + vhjb controller (BASELINE configs[4])"),
+        "linear": lambda: (LinearDynamics(D.linear_dynamics_config()), D.linear_vhjb_config(), "double integrator + vhjb controller"),
+    }[args.system]()
+    if args.integrator == "rk4":
+        dyn.integrator = _abi.RK4
+    ctl = VHJBController(dyn, ccfg, fused_value_grad=not args.torch_mlp)
     vf = ctl.value_function_approximator
     wgen = torch.Generator(device="cuda"); wgen.manual_seed(1234)
     vf.load_quadratic(ctl.P, noise=0.05, generator=wgen)
     gen = torch.Generator(device="cuda"); gen.manual_seed(rank)
     x0 = dyn.get_initial_state(B, generator=gen)
+    if args.system in ("quad2d", "nearhover"):
+        x0 = (x0 * 0.5).contiguous()             # start inside the observation box (the stock x0 box is as wide as it)
 
     n, m = dyn.get_dimension()
     sysh, task = dyn.system, ctl._task
@@ -110,7 +129,8 @@ def main():
                 if events is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                out = _ops.vhjb_rollout(sysh, task, desc, x_cur, k, T_max, done_step, t_first=t, log_traj=True, want_x_out=True)
+                out = _ops.vhjb_rollout(sysh, task, desc, x_cur, k, T_max, done_step, t_first=t, integrator=dyn.integrator, log_traj=True,
+                                        want_x_out=True)
                 if events is not None:
                     e1.record()
                     events.append((e0, e1, k))
@@ -143,7 +163,7 @@ def main():
         def step(t):
             s_, d_ = t % RING, (t + 1) % RING
             g = ctl.get_v_gradient(traj[s_])
-            _ops.vhjb_step(sysh, task, t, T_max, traj[s_], g, traj[d_], cost[s_], done[s_], done_step)
+            _ops.vhjb_step(sysh, task, t, T_max, traj[s_], g, traj[d_], cost[s_], done[s_], done_step, integrator=dyn.integrator)
 
         for t in range(W):
             step(t)
@@ -208,11 +228,12 @@ def main():
             roofline["traffic"] = rec * (B / float(1 << 20))
     other = kernel_ms
 
-    out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20", value=value, unit="env-steps/s", n_gpus=world,
+    out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20" if args.system == "cartpole" else
+               f"env-steps/sec (batched HJB rollouts), {args.system}", value=value, unit="env-steps/s", n_gpus=world,
                steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                data="synthetic",
-               config=dict(workload="cartpole balancing + vhjb controller (BASELINE configs[1])", batch_per_gpu=B, global_batch=B * world,
-                           state_dim=n, control_dim=m, integrator="euler", mlp="4-128-128-64 relu, no bias",
+               config=dict(workload=label, batch_per_gpu=B, global_batch=B * world,
+                           state_dim=n, control_dim=m, integrator=args.integrator, mlp=f"{n}-128-128-64 relu, no bias",
                            value_grad=("persistent fused rollout kernel (MFMA value net + step)" if fused else
                                        "fused HIP MFMA kernel + step kernel" if ctl.fused_value_grad else "PyTorch-ROCm matmuls + step kernel"),
                            live_fraction=live / (B * world * K), parallelism=f"env-shard x{world}, no data-path collective"),
@@ -245,8 +266,13 @@ def cpu_baseline(dyn, ctl, x0, sample_envs):
     nenv = sample_envs or int(min(x0.shape[0], max(512, rate * 12.0 / T)))
     xs = x0[:nenv].cpu().numpy().astype(np.float64)
     t0 = time.perf_counter(); r = O.vhjb_rollout(s, ctl._task, mlp, *Wts, xs, T, log=False); dt = time.perf_counter() - t0
-    return dict(value=r["live_steps"] / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{nenv} envs x {T} steps of the same workload (f64, OpenMP over envs), {dt:.1f} s")
+    multi = r["live_steps"] / dt
+    O.threads(1)                                 # the reference's own execution model: one environment at a time, one thread
+    n1 = max(64, nenv // (4 * cores))
+    t0 = time.perf_counter(); r1 = O.vhjb_rollout(s, ctl._task, mlp, *Wts, xs[:n1], T, log=False); dt1 = time.perf_counter() - t0
+    return dict(value=multi, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{nenv} envs x {T} steps of the same workload (f64, OpenMP over envs), {dt:.1f} s",
+                single_thread_value=r1["live_steps"] / dt1, single_thread_sample=f"{n1} envs x {T} steps, {dt1:.1f} s")
 
 
 if __name__ == "__main__":

@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the HIP library and the oracle are build artefacts (git-ignored): make sure both exist and are current
+    from q_learning_with_hjb_amd import build_library
+    build_library()
+    from oracle import oracle as O
+    O.build()
 
 
 def load_golden(name):
