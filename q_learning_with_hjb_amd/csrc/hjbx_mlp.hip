@@ -34,6 +34,7 @@
 using namespace hjbx;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 static constexpr int kH1 = 128, kH2 = 128, kH3 = 64;
 static constexpr int kLD1 = 129, kLD2 = 129, kLD3 = 65;  // odd LDS row strides (floats)
@@ -277,26 +278,26 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
     mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, c.w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
 #pragma unroll
     for (int t = 0; t < TL; ++t) {
-        float part[NP];
+        f32x2 part[NP / 2];  // packed pairs: one v_pk_fma_f32 per two rows of W1
 #pragma unroll
-        for (int k = 0; k < NP; ++k) part[k] = 0.f;
+        for (int k = 0; k < NP / 2; ++k) part[k] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const float dv = a1[t][kb][s] > 0.f ? d1[t][kb][s] : 0.f;
+                const f32x2 dv2{dv, dv};
 #pragma unroll
                 for (int q = 0; q < NP / 4; ++q) {
                     const float4 w = c.w1t[(32 * kb + perm(s)) * (NP / 4) + q];
-                    part[4 * q + 0] += w.x * dv;
-                    part[4 * q + 1] += w.y * dv;
-                    part[4 * q + 2] += w.z * dv;
-                    part[4 * q + 3] += w.w * dv;
+                    part[2 * q + 0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dv2, part[2 * q + 0]);
+                    part[2 * q + 1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dv2, part[2 * q + 1]);
                 }
             }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const float v = part[k] + __shfl_xor(part[k], 32, 64);
+            const float pk = part[k >> 1][k & 1];
+            const float v = pk + __shfl_xor(pk, 32, 64);
             g[t][k] = v / p.std[k] + 2.f * p.eps_s * e[t][k];
         }
     }
