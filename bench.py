@@ -123,7 +123,7 @@ def main():
 
         def run(nsteps, events=None):
             nonlocal x_cur, t
-            left = nsteps
+            left, out = nsteps, None
             while left > 0:
                 k = min(CHUNK, left)
                 if events is not None:
