@@ -513,8 +513,9 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
             return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_grad_f32: no HIP device");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    int64_t grid = (ngroups + WAVES - 1) / WAVES;
-    if (grid > n_cu) grid = n_cu;  // one resident workgroup per CU (106 KB of LDS each)
+    // one resident workgroup per CU (106 KB of LDS each); small batches are spread one tile group per CU
+    // rather than packed eight to a workgroup, so up to n_cu matrix pipes work on them
+    int64_t grid = ngroups < n_cu ? ngroups : n_cu;
     hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
                        (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
     hipError_t e = hipGetLastError();
@@ -575,8 +576,7 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
             return hjbx_set_error(HJBX_ENODEVICE, "hjbx_vhjb_rollout_f32: no HIP device");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    int64_t grid = (ngroups + WAVES - 1) / WAVES;
-    if (grid > n_cu) grid = n_cu;
+    int64_t grid = ngroups < n_cu ? ngroups : n_cu;  // as in launch_value_grad
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
     if (integrator == HJBX_EULER)
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
