@@ -189,12 +189,11 @@ template <typename T> struct Quad2D {
     HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
         T s, c;
         sincos_t(x[2], &s, &c);
-        const T ut = u[0] + u[1];
+        // f1 + f2 @ u with f2's rows written out (same operation order as the generic affine form)
         xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
         xd[3] = T(0) + ((-s / m) * u[0] + (-s / m) * u[1]);
         xd[4] = -g + ((c / m) * u[0] + (c / m) * u[1]);
         xd[5] = T(0) + ((r / I) * u[0] + (-r / I) * u[1]);
-        (void)ut;
     }
 };
 
