@@ -46,7 +46,7 @@ typedef enum hjbx_status {
 
 /* Which dynamics class of the reference the handle stands for. */
 typedef enum hjbx_system_kind {
-    HJBX_SYS_LINEAR = 0,    /* dynamics/linear.py:7-22      params = A (n*n row-major) then B (n*m) */
+    HJBX_SYS_LINEAR = 0,    /* dynamics/linear.py:7-22      params = A (n*n row-major), B (n*m) [, Ad (n*n), Bd (n*m) for HJBX_ZOH] */
     HJBX_SYS_CARTPOLE = 1,  /* dynamics/cartpole.py:10-64   params = mc, mp, l, g                    */
     HJBX_SYS_ACROBOT = 2,   /* dynamics/acrobot.py:19-81    params = m1, m2, l1, l2, I1, I2, g       */
     HJBX_SYS_QUAD2D = 3,    /* dynamics/quadrotors.py:9-70  params = m, r, I, g                      */
@@ -55,7 +55,10 @@ typedef enum hjbx_system_kind {
 
 typedef enum hjbx_integrator {
     HJBX_EULER = 0, /* x' = wrap(x + dt*xdot): the reference's integrator, dynamics_basic.py:120 (parity mode) */
-    HJBX_RK4 = 1    /* classic RK4 with zero-order-hold control, wrap applied once at the end (new mode)         */
+    HJBX_RK4 = 1,   /* classic RK4 with zero-order-hold control, wrap applied once at the end (new mode)         */
+    HJBX_ZOH = 2    /* LINEAR systems only: exact zero-order-hold step x' = Ad x + Bd u, the discretisation the
+                       reference's LQR / time-optimal notebooks use (scipy.signal.cont2discrete:
+                       examples/double_integrator_optimal_time.ipynb cell 4); needs Ad, Bd in the handle          */
 } hjbx_integrator;
 
 typedef enum hjbx_residual_mode {
@@ -66,11 +69,17 @@ typedef enum hjbx_residual_mode {
 typedef enum hjbx_controller_kind {
     HJBX_CTRL_LINEAR_FEEDBACK = 0, /* u = clip(-K e + uf): controller/lqr.py:25-26, quadrotors_model_based_controller.py:36-38, 73-75 */
     HJBX_CTRL_CARTPOLE_ENERGY = 1, /* controller/cartpole_energy_shaping.py:65-110 */
-    HJBX_CTRL_ACROBOT_ENERGY = 2   /* controller/acrobot_energy_shaping.py:74-121  */
+    HJBX_CTRL_ACROBOT_ENERGY = 2,  /* controller/acrobot_energy_shaping.py:74-121  */
+    HJBX_CTRL_DI_TIME_OPTIMAL = 3  /* double integrator (LINEAR n=2, m=1), analytic bang-bang law with its switching curve:
+                                      get_analytical_control, examples/double_integrator_optimal_time.ipynb cell 18;
+                                      u = 0 inside the target ball e'e <= eps_region, else +-umax */
 } hjbx_controller_kind;
 
 /* rollout flags */
 #define HJBX_ROLLOUT_TERMINATE 1u /* stop an environment when wrap(x-xf) leaves [obs_min, obs_max] (vhjb.py:176-181) */
+#define HJBX_ROLLOUT_STOP_AT_TARGET 2u /* stop an environment once e'e <= ctrl.eps_region, e = x - ctrl.xf, checked before
+                                          the control of each step (time-to-origin loops of the time-optimal notebook,
+                                          cell 9); done_step = index of that step */
 
 typedef struct hjbx_system hjbx_system; /* opaque */
 
@@ -100,7 +109,7 @@ typedef struct hjbx_controller {
     double Kes[3];      /* energy-shaping gains (cartpole [4,4,10], acrobot [1,2,1]) */
     double eps_energy;  /* CARTPOLE_ENERGY: |E-E(xf)| < eps_energy ... */
     double eps_state;   /* ... and ||(dtheta_err, dtheta_dot)|| < eps_state selects the LQR branch */
-    double eps_region;  /* ACROBOT_ENERGY */
+    double eps_region;  /* ACROBOT_ENERGY: LQR region; DI_TIME_OPTIMAL / STOP_AT_TARGET: squared radius of the target ball */
 } hjbx_controller;
 
 /* Value network of controller/vhjb.py:17-60 (no bias, BatchNorm off): device weight pointers,

@@ -26,7 +26,7 @@ typedef struct orc_system {
     int32_t kind, n, m, _pad;
     double dt;
     double umin[HJBX_MAX_M], umax[HJBX_MAX_M];
-    double p[HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M]; /* same packing as hjbx_system_create */
+    double p[2 * (HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M)]; /* same packing as hjbx_system_create (A, B [, Ad, Bd]) */
 } orc_system;
 
 /* value-network hyper-parameters (weights are passed as separate host arrays) */

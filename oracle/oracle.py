@@ -21,7 +21,7 @@ MAXN, MAXM = _abi.HJBX_MAX_N, _abi.HJBX_MAX_M
 
 class OrcSystem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("_pad", C.c_int32), ("dt", C.c_double),
-                ("umin", C.c_double * MAXM), ("umax", C.c_double * MAXM), ("p", C.c_double * (MAXN * MAXN + MAXN * MAXM))]
+                ("umin", C.c_double * MAXM), ("umax", C.c_double * MAXM), ("p", C.c_double * (2 * (MAXN * MAXN + MAXN * MAXM)))]
 
 
 class OrcMlp(C.Structure):
@@ -250,7 +250,7 @@ def vhjb_rollout(sys, task, mlp, W1, W2, W3, x0, T_max, integrator=0, dtype=np.f
     return dict(traj=traj, cost=cost, done_step=ds, live_steps=int(live))
 
 
-def rollout_feedback(sys, ctrl, x0, T_steps, task=None, integrator=0, terminate=False, dtype=np.float64, log=True):
+def rollout_feedback(sys, ctrl, x0, T_steps, task=None, integrator=0, terminate=False, dtype=np.float64, log=True, stop_at_target=False):
     sfx, dt = _dt(dtype)
     x0 = _a(x0, dt, (-1, sys.n)); B = x0.shape[0]
     traj = np.empty((T_steps + 1, B, sys.n), dt) if log else None
@@ -258,7 +258,7 @@ def rollout_feedback(sys, ctrl, x0, T_steps, task=None, integrator=0, terminate=
     cost = np.empty((T_steps + 1, B), dt) if (log and task is not None) else None
     total = np.empty((B,), dt) if task is not None else None
     ds = np.empty((B,), np.int32); xf = np.empty_like(x0)
-    live = getattr(lib(), f"orc_rollout_feedback_{sfx}")(_r(sys.c), _r(task), _r(ctrl), C.c_int(integrator), C.c_uint32(1 if terminate else 0),
+    live = getattr(lib(), f"orc_rollout_feedback_{sfx}")(_r(sys.c), _r(task), _r(ctrl), C.c_int(integrator), C.c_uint32((1 if terminate else 0) | (2 if stop_at_target else 0)),
                                                         C.c_int(T_steps), _p(x0), _p(traj), _p(ulog), _p(cost), _p(ds), _p(total), _p(xf),
                                                         C.c_int64(B))
     return dict(traj=traj, u=ulog, cost=cost, total_cost=total, done_step=ds, x_final=xf, live_steps=int(live))

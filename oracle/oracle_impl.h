@@ -158,6 +158,18 @@ static void FN(simulate1)(const orc_system* s, int integrator, const REAL* x, co
     const REAL dt = (REAL)s->dt;
     REAL uc[HJBX_MAX_M], k1[HJBX_MAX_N];
     FN(clip_u)(s, u, uc);
+    if (integrator == HJBX_ZOH) { /* x' = Ad x + Bd u: examples/double_integrator_optimal_time.ipynb cell 4 (LINEAR only) */
+        const int m = s->m;
+        const double* Ad = s->p + n * n + n * m; const double* Bd = Ad + n * n;
+        for (int i = 0; i < n; ++i) {
+            REAL acc = 0, bu = 0;
+            for (int j = 0; j < n; ++j) acc += (REAL)Ad[i * n + j] * x[j];
+            for (int j = 0; j < m; ++j) bu += (REAL)Bd[i * m + j] * uc[j];
+            xn[i] = acc + bu;
+        }
+        FN(wrap1)(s, xn);
+        return;
+    }
     FN(xdot1)(s, x, uc, k1);
     if (integrator == HJBX_EULER) {
         for (int i = 0; i < n; ++i) xn[i] = x[i] + k1[i] * dt;
@@ -354,6 +366,11 @@ static void FN(controller1)(const orc_system* s, const hjbx_controller* c, const
             const REAL ddq2 = -cth / l * ddq1 - g * sth / l;
             ur[0] = (mc + mp) * ddq1 + mp * l * cth * ddq2 - mp * l * sth * x[3] * x[3];
         }
+    } else if (c->kind == HJBX_CTRL_DI_TIME_OPTIMAL) { /* get_analytical_control, double_integrator_optimal_time.ipynb cell 18 */
+        const REAL p0 = x[0] - (REAL)c->xf[0], v0 = x[1] - (REAL)c->xf[1], a = (REAL)s->umax[0];
+        if (p0 * p0 + v0 * v0 <= (REAL)c->eps_region) ur[0] = 0;
+        else if ((v0 < 0 && p0 <= (REAL)0.5 * v0 * v0 / a) || (v0 >= 0 && p0 < -(REAL)0.5 * v0 * v0 / a)) ur[0] = a;
+        else ur[0] = -a;
     } else { /* acrobot_energy_shaping.py:74-121 */
         REAL dx[4];
         dx[0] = FN(wrap_angle)(x[0] - (REAL)c->xf[0]);
@@ -584,9 +601,15 @@ int64_t FN(orc_rollout_feedback)(const orc_system* s, const hjbx_task* t, const 
             for (int j = 0; j < m; ++j) u[j] = 0;
             if (ds < 0) {
                 const int term = (flags & HJBX_ROLLOUT_TERMINATE) != 0;
-                if (step == T_steps || (term && FN(out_of_box)(s, t, x))) {
-                    if (t) cst = FN(termination_cost1)(s, t, x);
-                    if (term || step == T_steps) ds = step;
+                int reached = 0;
+                if (flags & HJBX_ROLLOUT_STOP_AT_TARGET) { /* notebook cell 9: if x.T @ x <= metric: record t; break */
+                    REAL d2 = 0;
+                    for (int i = 0; i < n; ++i) d2 += (x[i] - (REAL)c->xf[i]) * (x[i] - (REAL)c->xf[i]);
+                    reached = d2 <= (REAL)c->eps_region;
+                }
+                if (step == T_steps || reached || (term && FN(out_of_box)(s, t, x))) {
+                    if (t && !reached) cst = FN(termination_cost1)(s, t, x);
+                    ds = step;
                 } else {
                     FN(controller1)(s, c, x, u);
                     if (t) cst = FN(running_cost1)(s, t, x, u) * (REAL)s->dt;

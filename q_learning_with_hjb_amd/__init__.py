@@ -5,7 +5,7 @@ Drop-in for the hot path of HaoxiangYou/Q_Learning_with_HJB: the `Dynamics` / `C
 hand-written gfx950 HIP kernel behind a C ABI (include/hjbx.h, csrc/).  See DESIGN.md.
 """
 from . import _abi
-from ._abi import EULER, RK4, RESIDUAL_NORMALISED, RESIDUAL_RAW, build_library
+from ._abi import EULER, RK4, ZOH, RESIDUAL_NORMALISED, RESIDUAL_RAW, build_library
 
-__all__ = ["_abi", "EULER", "RK4", "RESIDUAL_NORMALISED", "RESIDUAL_RAW", "build_library"]
+__all__ = ["_abi", "EULER", "RK4", "ZOH", "RESIDUAL_NORMALISED", "RESIDUAL_RAW", "build_library"]
 __version__ = "0.1.0"

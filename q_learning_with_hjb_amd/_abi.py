@@ -17,10 +17,11 @@ HJBX_MAX_M = 3
 
 # enums of include/hjbx.h
 SYS_LINEAR, SYS_CARTPOLE, SYS_ACROBOT, SYS_QUAD2D, SYS_NEARHOVER = range(5)
-EULER, RK4 = 0, 1
+EULER, RK4, ZOH = 0, 1, 2
 RESIDUAL_NORMALISED, RESIDUAL_RAW = 0, 1
-CTRL_LINEAR_FEEDBACK, CTRL_CARTPOLE_ENERGY, CTRL_ACROBOT_ENERGY = 0, 1, 2
+CTRL_LINEAR_FEEDBACK, CTRL_CARTPOLE_ENERGY, CTRL_ACROBOT_ENERGY, CTRL_DI_TIME_OPTIMAL = 0, 1, 2, 3
 ROLLOUT_TERMINATE = 1
+ROLLOUT_STOP_AT_TARGET = 2
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")

@@ -191,7 +191,7 @@ def controller(sys, ctrl, x):
 
 
 def rollout_feedback(sys, ctrl, x0, T_steps, task=None, integrator=_abi.EULER, terminate=False, log_traj=True, log_u=False,
-                     log_cost=False):
+                     log_cost=False, stop_at_target=False):
     """Whole closed loop in one kernel launch.  Returns a dict of device tensors (time-major)."""
     B = x0.shape[0]
     _chk(x0, "x0", (B, sys.n))
@@ -202,7 +202,7 @@ def rollout_feedback(sys, ctrl, x0, T_steps, task=None, integrator=_abi.EULER, t
     total = torch.empty((B,), dtype=dt, device=dev) if task is not None else None
     done_step = torch.empty((B,), dtype=torch.int32, device=dev)
     x_final = torch.empty_like(x0)
-    flags = _abi.ROLLOUT_TERMINATE if terminate else 0
+    flags = (_abi.ROLLOUT_TERMINATE if terminate else 0) | (_abi.ROLLOUT_STOP_AT_TARGET if stop_at_target else 0)
     check(_fn("rollout_feedback", x0)(sys.ptr, ref(task), ref(ctrl), int(integrator), flags, int(T_steps), _p(x0), _p(traj),
                                       _p(ulog), _p(cost), _p(done_step), _p(total), _p(x_final), B, _stream()))
     return dict(traj=traj, u=ulog, cost=cost, done_step=done_step, total_cost=total, x_final=x_final)

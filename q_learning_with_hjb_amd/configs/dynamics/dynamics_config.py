@@ -63,8 +63,20 @@ class LinearDynamicsConfig(DynamicsConfig):
         self.A, self.B = _f32(self.A), _f32(self.B)
         super().__post_init__()
 
+    def discretize(self):
+        """(Ad, Bd): exact zero-order-hold discretisation over dt, expm([[A, B], [0, 0]] dt) -- what
+        scipy.signal.cont2discrete returns in the reference's notebooks."""
+        import scipy.linalg
+        n, m = self.A.shape[0], self.B.shape[1]
+        aug = np.zeros((n + m, n + m))
+        aug[:n, :n] = self.A.astype(np.float64)
+        aug[:n, n:] = self.B.astype(np.float64)
+        E = scipy.linalg.expm(aug * float(self.dt))
+        return E[:n, :n].copy(), E[:n, n:].copy()
+
     def system_params(self):
-        return np.concatenate([self.A.astype(np.float64).ravel(), self.B.astype(np.float64).ravel()])
+        Ad, Bd = self.discretize()   # A, B, then Ad, Bd for the HJBX_ZOH integrator
+        return np.concatenate([self.A.astype(np.float64).ravel(), self.B.astype(np.float64).ravel(), Ad.ravel(), Bd.ravel()])
 
 
 @configurable

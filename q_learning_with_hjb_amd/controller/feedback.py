@@ -24,15 +24,16 @@ class DeviceFeedbackController(Controller):
         u = _ops.controller(self.dynamics.system, self._descriptor(), t)
         return _from_device(u, one, kind)
 
-    def rollout(self, x0, steps, task=None, terminate=False, log_traj=True, log_u=True, log_cost=False):
+    def rollout(self, x0, steps, task=None, terminate=False, log_traj=True, log_u=True, log_cost=False, stop_at_target=False):
         """Closed loop `for t: u = self(x); x = simulate(x, u)` for `steps` steps, fused in one kernel.
 
         x0: (B, n) (or (n,)).  Returns a dict with time-major `traj` (steps+1, B, n), `u` (steps, B, m),
-        optional `cost`, `total_cost`, `done_step`, `x_final`; numpy in -> numpy out."""
+        optional `cost`, `total_cost`, `done_step`, `x_final`; numpy in -> numpy out.  `stop_at_target` ends an
+        environment once it is inside the controller's target ball (`done_step` = that step index)."""
         t, one, kind = _to_device(x0)
         out = _ops.rollout_feedback(self.dynamics.system, self._descriptor(), t, int(steps), task=task,
                                     integrator=self.dynamics.integrator, terminate=terminate, log_traj=log_traj, log_u=log_u,
-                                    log_cost=log_cost)
+                                    log_cost=log_cost, stop_at_target=stop_at_target)
         if kind == "cuda":
             return out
         return {k: (None if v is None else (v.cpu().numpy() if kind == "numpy" else v.cpu())) for k, v in out.items()}

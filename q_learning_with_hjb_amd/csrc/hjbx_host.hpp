@@ -8,6 +8,10 @@
 
 using namespace hjbx;
 
+// compile-time facts about a device system type, used to instantiate system-specific kernels only where they exist
+template <typename S> struct is_linear { static constexpr bool value = S::kHasZoh; };                            // HJBX_ZOH stepping
+template <typename S> struct is_di { static constexpr bool value = S::kHasZoh && S::N == 2 && S::M == 1; };  // double integrator
+
 template <typename T, int M> inline Limits<T, M> make_limits(const hjbx_system* s) {
     Limits<T, M> l;
     for (int j = 0; j < M; ++j) { l.umin[j] = (T)s->umin[j]; l.umax[j] = (T)s->umax[j]; }
@@ -46,6 +50,9 @@ template <typename T, int N, int M> inline Linear<T, N, M> make_linear(const hjb
     Linear<T, N, M> l;
     for (int i = 0; i < N * N; ++i) l.A[i] = (T)s->p[i];
     for (int i = 0; i < N * M; ++i) l.Bm[i] = (T)s->p[N * N + i];
+    const bool zoh = s->n_params == 2 * (N * N + N * M);
+    for (int i = 0; i < N * N; ++i) l.Ad[i] = zoh ? (T)s->p[N * N + N * M + i] : T(0);
+    for (int i = 0; i < N * M; ++i) l.Bd[i] = zoh ? (T)s->p[2 * N * N + N * M + i] : T(0);
     return l;
 }
 
@@ -70,3 +77,15 @@ template <typename T, typename F> inline bool with_system(const hjbx_system* s, 
     return false;
 }
 
+
+// integrator argument check shared by every stepping entry point: HJBX_ZOH needs a LINEAR handle created with Ad, Bd
+inline int check_integrator(const hjbx_system* s, int integ, const char* who) {
+    if (integ == HJBX_EULER || integ == HJBX_RK4) return HJBX_OK;
+    if (integ == HJBX_ZOH) {
+        if (s->kind != HJBX_SYS_LINEAR) return hjbx_set_error(HJBX_EUNSUPPORTED, "%s: HJBX_ZOH exists for LINEAR systems only", who);
+        if (s->n_params != 2 * (s->n * s->n + s->n * s->m))
+            return hjbx_set_error(HJBX_EINVAL, "%s: HJBX_ZOH needs a system created with Ad, Bd (2(n*n+n*m) parameters)", who);
+        return HJBX_OK;
+    }
+    return hjbx_set_error(HJBX_EINVAL, "%s: unknown integrator %d", who, integ);
+}

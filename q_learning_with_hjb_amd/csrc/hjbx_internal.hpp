@@ -7,7 +7,7 @@ struct hjbx_system {
     int kind, n, m;
     double dt;
     double umin[HJBX_MAX_M], umax[HJBX_MAX_M];
-    double p[HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M];  // packing documented at hjbx_system_kind
+    double p[2 * (HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M)];  // packing documented at hjbx_system_kind
     int n_params;
 };
 

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_feedback(S sys, TaskP<T, S::
     T x[N], xn[N], u[M];
     RowIO<T, N>::load(x0, i, x);
     const bool term = (flags & HJBX_ROLLOUT_TERMINATE) != 0;
+    const bool stop_at_target = (flags & HJBX_ROLLOUT_STOP_AT_TARGET) != 0;
     int ds = -1;
     T tot = T(0);
     for (int t = 0; t <= T_steps; ++t) {
@@ -384,8 +385,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout_feedback(S sys, TaskP<T, S::
                 error_coords(sys, tk.xf, x, e);
                 oob = term && out_of_box<S, T>(tk, e);
             }
-            if (t == T_steps || oob) {
-                if (has_task && term) cst = quad_form<N>(tk.P, e);
+            bool reached = false;
+            if (stop_at_target) {  // cell 9 of the time-optimal notebook: `if x.T @ x <= metric: record t; break`
+                T d2 = T(0);
+#pragma unroll
+                for (int k = 0; k < N; ++k) d2 += (x[k] - c.xf[k]) * (x[k] - c.xf[k]);
+                reached = d2 <= c.eps_region;
+            }
+            if (t == T_steps || oob || reached) {
+                if (has_task && term && !reached) cst = quad_form<N>(tk.P, e);
                 ds = t;
             } else {
                 controller_eval<CK>(sys, c, lim, x, u);
@@ -456,14 +464,16 @@ template <typename T> static int xdot_impl(const hjbx_system* sys, const T* x, c
 template <typename T>
 static int simulate_impl(const hjbx_system* sys, int integ, const T* x, const T* u, T* xn, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(xn, sys->n);
-    HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
+    if (int rc = check_integrator(sys, integ, "hjbx_simulate")) return rc;
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto lim = make_limits<T, SS::M>(sys);
             if (integ == HJBX_EULER)
                 hipLaunchKernelGGL((k_simulate<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
-            else
+            else if (integ == HJBX_RK4)
                 hipLaunchKernelGGL((k_simulate<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
+            else if constexpr (is_linear<SS>::value)
+                hipLaunchKernelGGL((k_simulate<2, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
         })) return unsupported(sys);
     return check_launch("hjbx_simulate");
 }
@@ -578,7 +588,7 @@ template <typename T>
 static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int integ, int t, int T_max, const T* x, const T* g,
                           T* xn, T* u_out, T* cost_t, T* done_t, int32_t* done_step, T* resid_t, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL");
-    HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
+    if (int rc = check_integrator(sys, integ, "hjbx_vhjb_step")) return rc;
     HJBX_REQUIRE(t >= 0 && T_max >= 0, "negative step index");
     HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(xn, sys->n); HJBX_CHECK_OPT(u_out, sys->m);
     HJBX_REQUIRE(cost_t && done_t && done_step, "cost_t/done_t/done_step must be non-NULL");
@@ -589,8 +599,11 @@ static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int int
             if (integ == HJBX_EULER)
                 hipLaunchKernelGGL((k_vhjb_step<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
                                    g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
-            else
+            else if (integ == HJBX_RK4)
                 hipLaunchKernelGGL((k_vhjb_step<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
+                                   g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
+            else if constexpr (is_linear<SS>::value)
+                hipLaunchKernelGGL((k_vhjb_step<2, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
                                    g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
         })) return unsupported(sys);
     return check_launch("hjbx_vhjb_step");
@@ -603,7 +616,9 @@ template <typename T> struct is_acrobot<Acrobot<T>> { static constexpr bool valu
 
 static int check_ctrl(const hjbx_system* sys, const hjbx_controller* c) {
     HJBX_REQUIRE(c, "controller is NULL");
-    HJBX_REQUIRE(c->kind >= HJBX_CTRL_LINEAR_FEEDBACK && c->kind <= HJBX_CTRL_ACROBOT_ENERGY, "unknown controller kind %d", c->kind);
+    HJBX_REQUIRE(c->kind >= HJBX_CTRL_LINEAR_FEEDBACK && c->kind <= HJBX_CTRL_DI_TIME_OPTIMAL, "unknown controller kind %d", c->kind);
+    if (c->kind == HJBX_CTRL_DI_TIME_OPTIMAL && !(sys->kind == HJBX_SYS_LINEAR && sys->n == 2 && sys->m == 1))
+        return hjbx_set_error(HJBX_EINVAL, "the time-optimal bang-bang controller needs the double integrator (LINEAR, n=2, m=1)");
     if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY && sys->kind != HJBX_SYS_CARTPOLE)
         return hjbx_set_error(HJBX_EINVAL, "cartpole energy-shaping controller needs a cartpole system");
     if (c->kind == HJBX_CTRL_ACROBOT_ENERGY && sys->kind != HJBX_SYS_ACROBOT)
@@ -623,6 +638,12 @@ static int controller_impl(const hjbx_system* sys, const hjbx_controller* c, con
             if constexpr (is_cartpole<SS>::value) {
                 if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY) {
                     hipLaunchKernelGGL((k_controller<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, cp, lim, x, u, B);
+                    return;
+                }
+            }
+            if constexpr (is_di<SS>::value) {
+                if (c->kind == HJBX_CTRL_DI_TIME_OPTIMAL) {
+                    hipLaunchKernelGGL((k_controller<3, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, cp, lim, x, u, B);
                     return;
                 }
             }
@@ -651,6 +672,9 @@ static void launch_rollout(const hjbx_system* sys, SS S, const hjbx_task* task, 
     if constexpr (is_cartpole<SS>::value) {
         if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY) { HJBX_LAUNCH_RO(1); return; }
     }
+    if constexpr (is_di<SS>::value) {
+        if (c->kind == HJBX_CTRL_DI_TIME_OPTIMAL) { HJBX_LAUNCH_RO(3); return; }
+    }
     if constexpr (is_acrobot<SS>::value) {
         if (c->kind == HJBX_CTRL_ACROBOT_ENERGY) { HJBX_LAUNCH_RO(2); return; }
     }
@@ -664,9 +688,9 @@ static int rollout_feedback_impl(const hjbx_system* sys, const hjbx_task* task, 
                                  T* x_final, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B);
     if (int rc = check_ctrl(sys, c)) return rc;
-    HJBX_REQUIRE(integ == HJBX_EULER || integ == HJBX_RK4, "unknown integrator %d", integ);
+    if (int rc = check_integrator(sys, integ, "hjbx_rollout_feedback")) return rc;
     HJBX_REQUIRE(T_steps >= 0, "negative horizon");
-    HJBX_REQUIRE((flags & ~HJBX_ROLLOUT_TERMINATE) == 0, "unknown rollout flags 0x%x", flags);
+    HJBX_REQUIRE((flags & ~(HJBX_ROLLOUT_TERMINATE | HJBX_ROLLOUT_STOP_AT_TARGET)) == 0, "unknown rollout flags 0x%x", flags);
     HJBX_REQUIRE(task || !(flags & HJBX_ROLLOUT_TERMINATE), "HJBX_ROLLOUT_TERMINATE needs a task");
     HJBX_REQUIRE(task || (!cost && !total_cost), "cost outputs need a task");
     HJBX_CHECK_ROWS(x0, sys->n); HJBX_CHECK_OPT(traj, sys->n); HJBX_CHECK_OPT(u_log, sys->m); HJBX_CHECK_OPT(x_final, sys->n);
@@ -674,8 +698,10 @@ static int rollout_feedback_impl(const hjbx_system* sys, const hjbx_task* task, 
             using SS = decltype(S);
             if (integ == HJBX_EULER)
                 launch_rollout<0, SS, T>(sys, S, task, c, flags, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B, st);
-            else
+            else if (integ == HJBX_RK4)
                 launch_rollout<1, SS, T>(sys, S, task, c, flags, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B, st);
+            else if constexpr (is_linear<SS>::value)
+                launch_rollout<2, SS, T>(sys, S, task, c, flags, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B, st);
         })) return unsupported(sys);
     return check_launch("hjbx_rollout_feedback");
 }
@@ -728,7 +754,8 @@ int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, co
     default: return hjbx_set_error(HJBX_EINVAL, "unknown system kind %d", kind);
     }
     HJBX_REQUIRE(n == en && m == em, "system kind %d has n=%d m=%d, got n=%d m=%d", kind, en, em, n, m);
-    HJBX_REQUIRE(n_params == ep, "system kind %d takes %d parameters, got %d", kind, ep, n_params);
+    HJBX_REQUIRE(n_params == ep || (kind == HJBX_SYS_LINEAR && n_params == 2 * ep),
+                 "system kind %d takes %d parameters%s, got %d", kind, ep, kind == HJBX_SYS_LINEAR ? " (or twice that with Ad, Bd)" : "", n_params);
     for (int j = 0; j < m; ++j) HJBX_REQUIRE(umin[j] <= umax[j], "umin[%d] > umax[%d]", j, j);
     hjbx_system* s = new (std::nothrow) hjbx_system();
     if (!s) return hjbx_set_error(HJBX_EINVAL, "out of host memory");

@@ -581,8 +581,11 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     if (integrator == HJBX_EULER)
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
                            W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
-    else
+    else if (integrator == HJBX_RK4)
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<1, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
+                           W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
+    else if constexpr (S::kHasZoh)
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<2, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
                            W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_vhjb_rollout_f32: %s", hipGetErrorString(e));
@@ -594,7 +597,7 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
                                      float* resid, int32_t* done_step, float* x_out, int64_t B, void* stream) {
     if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: NULL system, task or mlp descriptor");
     if (B < 0 || n_steps < 0 || t_first < 0 || T_max < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: negative size or step index");
-    if (integrator != HJBX_EULER && integrator != HJBX_RK4) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: unknown integrator %d", integrator);
+    if (int rc = check_integrator(sys, integrator, "hjbx_vhjb_rollout_f32")) return rc;
     if (B == 0) return HJBX_OK;
     if (!x || !cost || !done || !done_step || !mlp->W1 || !mlp->W2 || !mlp->W3)
         return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: x, cost, done, done_step and the weights must be non-NULL");

@@ -62,8 +62,23 @@ template <typename T> HJBX_DEV T clamp_t(T v, T lo, T hi) {  // np.clip: min(max
 // ---- Linear: dynamics/linear.py:7-22 --------------------------------------------------------------
 template <typename T, int N_, int M_> struct Linear {
     static constexpr int N = N_, M = M_;
+    static constexpr bool kHasZoh = true;
     T A[N * N], Bm[N * M];
+    T Ad[N * N], Bd[N * M];  // exact zero-order-hold discretisation over dt (HJBX_ZOH); zero when the handle has none
     HJBX_DEV void wrap(T*) const {}
+    // x' = Ad x + Bd u  (scipy.signal.cont2discrete, examples/double_integrator_optimal_time.ipynb cell 4)
+    HJBX_DEV void zoh_step(const T* x, const T* u, T* xn) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += Ad[i * N + j] * x[j];
+            T bu = T(0);
+#pragma unroll
+            for (int j = 0; j < M; ++j) bu += Bd[i * M + j] * u[j];
+            xn[i] = acc + bu;
+        }
+    }
     HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -93,6 +108,7 @@ template <typename T, int N_, int M_> struct Linear {
 // D = mc + mp s^2;  f1 = [xd, thd, (mp l thd^2 s + mp g s c)/D, -(mp l thd^2 s c + (mc+mp) g s)/(l D)]
 // f2 = [0, 0, 1/D, -c/(l D)]      (theta = pi is upright)
 template <typename T> struct Cartpole {
+    static constexpr bool kHasZoh = false;
     static constexpr int N = 4, M = 1;
     T mc, mp, l, g;
     HJBX_DEV void wrap(T* x) const { x[1] = wrap_angle(x[1]); }
@@ -120,6 +136,7 @@ template <typename T> struct Cartpole {
 
 // ---- Acrobot: dynamics/acrobot.py:39-81 (constructor is stale upstream; math only) -----------------
 template <typename T> struct Acrobot {
+    static constexpr bool kHasZoh = false;
     static constexpr int N = 4, M = 1;
     T m1, m2, l1, l2, I1, I2, g;
     HJBX_DEV void wrap(T* x) const { x[0] = wrap_angle(x[0]); x[1] = wrap_angle(x[1]); }
@@ -173,6 +190,7 @@ template <typename T> struct Acrobot {
 
 // ---- Quadrotors2D: dynamics/quadrotors.py:17-70 ---------------------------------------------------
 template <typename T> struct Quad2D {
+    static constexpr bool kHasZoh = false;
     static constexpr int N = 6, M = 2;
     T m, r, I, g;
     HJBX_DEV void wrap(T* x) const { x[2] = wrap_angle(x[2]); }
@@ -199,6 +217,7 @@ template <typename T> struct Quad2D {
 
 // ---- NearHoverQuadcopter: dynamics/quadrotors.py:118-170 ------------------------------------------
 template <typename T> struct NearHover {
+    static constexpr bool kHasZoh = false;
     static constexpr int N = 10, M = 3;
     T g, m, kT, n0;
     HJBX_DEV void wrap(T* x) const { x[3] = wrap_angle(x[3]); x[4] = wrap_angle(x[4]); }
@@ -241,6 +260,12 @@ template <typename T, int M> HJBX_DEV void clip_u(const Limits<T, M>& lim, const
 // Dynamics.simulate body after the clip (dynamics_basic.py:120); RK4 is this library's extension.
 template <int INTEG, typename S, typename T> HJBX_DEV void integrate(const S& sys, T dt, const T* x, const T* u, T* xn) {
     constexpr int N = S::N;
+    if constexpr (INTEG == 2) {  // HJBX_ZOH: linear systems only (the host refuses it elsewhere)
+        static_assert(S::kHasZoh, "zero-order-hold stepping exists for LinearDynamics only");
+        sys.zoh_step(x, u, xn);
+        sys.wrap(xn);
+        return;
+    }
     T k1[N];
     sys.xdot(x, u, k1);
     if constexpr (INTEG == 0) {
@@ -407,6 +432,14 @@ HJBX_DEV void controller_eval(const S& sys, const CtrlP<T, S::N, S::M>& c, const
             const T ddq2 = -cth / sys.l * ddq1 - sys.g * sth / sys.l;
             ur[0] = (sys.mc + sys.mp) * ddq1 + sys.mp * sys.l * cth * ddq2 - sys.mp * sys.l * sth * x[3] * x[3];
         }
+    } else if constexpr (CK == 3) {
+        // double integrator, analytic minimum-time law (examples/double_integrator_optimal_time.ipynb cell 18):
+        // 0 inside the target ball, else +a above / -a below the switching curve p = -v|v|/(2a), a = umax
+        const T p0 = x[0] - c.xf[0], v0 = x[1] - c.xf[1];
+        const T a = lim.umax[0];
+        if (p0 * p0 + v0 * v0 <= c.eps_region) ur[0] = T(0);
+        else if ((v0 < T(0) && p0 <= T(0.5) * v0 * v0 / a) || (v0 >= T(0) && p0 < -T(0.5) * v0 * v0 / a)) ur[0] = a;
+        else ur[0] = -a;
     } else {
         T dx[4];
         dx[0] = wrap_angle(x[0] - c.xf[0]);

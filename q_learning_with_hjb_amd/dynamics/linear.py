@@ -15,6 +15,7 @@ class LinearDynamics(Dynamics):
         assert config.A.shape[0] == config.A.shape[1]
         self.A = config.A
         self.B = config.B
+        self.A_d, self.B_d = config.discretize()   # used when `self.integrator = ZOH`
         super().__init__(config)
 
     def _system_params(self, config):

@@ -509,3 +509,41 @@ def test_abi_argument_validation():
     assert g.shape == (16, 4)
     with pytest.raises(ValueError, match="normalization_std"):
         make_vhjb_config("cartpole", normalization_std=[1, 0, 1, 1])
+
+
+def _double_integrator(dt=0.01, umax=1.0):
+    from q_learning_with_hjb_amd.configs.defaults import linear_dynamics_config
+    from q_learning_with_hjb_amd.dynamics.linear import LinearDynamics
+    return LinearDynamics(linear_dynamics_config(dt=dt, umin=[-umax], umax=[umax]))
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_zoh_integrator_and_time_optimal_controller(prec):
+    """HJBX_ZOH (exact discretisation of LinearDynamics) and the analytic minimum-time law of the double integrator:
+    kernels vs oracle, and the closed loop against the reference's .mat ground truth."""
+    tdt, ndt, tol = DT[prec]
+    d = _double_integrator()
+    d.integrator = _abi.ZOH
+    s = O.System.from_dynamics(d)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (1000, 2)); u = rng.uniform(-1.5, 1.5, (1000, 1))
+    xd, ud = dev(x, tdt), dev(u, tdt)
+    check(_ops.simulate(d.system, xd, ud, _abi.ZOH), O.simulate(s, xd.cpu().numpy().astype(np.float64), ud.cpu().numpy().astype(np.float64),
+                                                              integrator=_abi.ZOH), tol)
+    from q_learning_with_hjb_amd.controller.time_optimal import DoubleIntegratorTimeOptimalController
+    c = DoubleIntegratorTimeOptimalController(d)
+    desc = c._descriptor()
+    check(_ops.controller(d.system, desc, xd), O.controller(s, desc, xd.cpu().numpy().astype(np.float64)), tol)
+    g = load_golden("di_time_optimal")
+    P, V = np.meshgrid(g["pos"], g["vel"], indexing="ij")
+    x0 = np.stack([P.ravel(), V.ravel()], 1)
+    t_reach = c.time_to_target(x0.astype(ndt), max_time=6.0).reshape(101, 101)      # numpy in -> numpy out, one launch
+    ref = O.rollout_feedback(s, desc, x0.astype(ndt).astype(np.float64), 600, integrator=_abi.ZOH, stop_at_target=True, log=False)
+    agree = (np.round(t_reach / 0.01).astype(np.int64).ravel() == ref["done_step"])
+    assert agree.mean() > (0.999 if prec == "f64" else 0.9)       # bang-bang switching: fp32 can flip a sign next to the curve
+    err = t_reach - g["attr"]
+    assert np.abs(err).mean() < 0.12 and np.abs(err).max() < 0.45 and np.median(np.abs(err)) < 0.03
+    # ZOH is refused where it does not exist
+    cp = make_dynamics("cartpole")
+    with pytest.raises(NotImplementedError, match="LINEAR"):
+        _ops.simulate(cp.system, torch.zeros((4, 4), device="cuda", dtype=tdt), torch.zeros((4, 1), device="cuda", dtype=tdt), _abi.ZOH)

@@ -271,6 +271,18 @@ def main():
     assert np.allclose(care["eye2_P"], 2.41421356 * np.eye(2), atol=1e-7)   # notebook cell 4 anchor
     data["care"] = care
 
+    # ---- time-optimal double integrator: the reference's own ground-truth data file ---------------------------
+    # examples/data/...level_set_methods.mat (loaded in examples/double_integrator_optimal_time.ipynb cell 18): `attr` = analytic
+    # minimum time to reach the target, `mttr` = the level-set solution, on the 101 x 101 grid [-1,1]^2 indexed [position, velocity].
+    # Only the numeric arrays are copied (scipy.io.loadmat parses, it executes nothing).
+    import scipy.io
+    mat = scipy.io.loadmat(os.path.join(REF, "examples", "data",
+                                        "time_optimal_control_for_double_integrator_results_from_level_set_methods.mat"))
+    grid = mat["gridOut"]
+    lo, hi, N = grid["min"][0][0].ravel(), grid["max"][0][0].ravel(), grid["N"][0][0].ravel()
+    data["di_time_optimal"] = dict(attr=mat["attr"].astype(np.float64), mttr=mat["mttr"].astype(np.float64),
+                                   pos=np.linspace(lo[0], hi[0], int(N[0])), vel=np.linspace(lo[1], hi[1], int(N[1])))
+
     for k, rec in data.items():
         np.savez(os.path.join(out, f"{k}.npz"), **{kk: np.asarray(vv) for kk, vv in rec.items()})
     with open(os.path.join(out, "spot_values.json"), "w") as f:
