@@ -217,8 +217,6 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
             z[t][k] = (e[t][k] - p.mean[k]) / p.std[k];
         }
     }
-    // All element-wise work (ReLU, mask application, 2y, |y|^2) is done inside the B-operand fetch of the NEXT
-    // product, one or two instructions per MFMA group.
     float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
 
     // ---- layer 1: H1' (128 x 32) = W1' (128 x N) . Z' (N x 32) --------------------------------------
@@ -226,48 +224,63 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
     zero_acc(a1);
     mfma_chain<OffW1F, N / 2, 4, 2, TL>(a1, ring4, c.w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
 
+    // Element-wise work between the products (ReLU, mask, 2y, |y|^2) is done in place on the accumulators in short
+    // VALU-only passes BEFORE each chain: those overlap the SIMD partner's MFMAs, whereas every instruction issued
+    // inside a chain delays this wave's next MFMA (~4 cycles each, tools/ubench/mfma_mix.hip).  Inside a chain a step
+    // is then 4 ds_read_b32 + 1 counted wait + 4 MFMAs.
+
     // ---- layer 2: H2' (128 x 32) = W2' . relu(H1') ---------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[t][fb][r] = relu1(a1[t][fb][r]);
     f32x16 a2[TL][4];
     zero_acc(a2);
-    mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, c.w2f, [&](int st, int t) { return relu1(a1[t][st >> 4][st & 15]); });
+    mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, c.w2f, [&](int st, int t) { return a1[t][st >> 4][st & 15]; });
 
     // ---- layer 3: Y' (64 x 32) = W3' . relu(H2') ------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[t][fb][r] = relu1(a2[t][fb][r]);  // relu(a) > 0 <=> a > 0: still the mask for backward 2
     f32x16 y[TL][2];
     zero_acc(y);
-    mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, c.w3f, [&](int st, int t) { return relu1(a2[t][st >> 4][st & 15]); });
+    mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, c.w3f, [&](int st, int t) { return a2[t][st >> 4][st & 15]; });
 
     float vpart[TL];
 #pragma unroll
-    for (int t = 0; t < TL; ++t) vpart[t] = 0.f;
-    if (!want_grad) {  // value only
+    for (int t = 0; t < TL; ++t) {
+        vpart[t] = 0.f;
 #pragma unroll
-        for (int t = 0; t < TL; ++t) {
+        for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) vpart[t] += y[t][ob][r] * y[t][ob][r];
-            V[t] = vpart[t] + __shfl_xor(vpart[t], 32, 64) + p.eps_s * ee[t];
-        }
-        return;
+            for (int r = 0; r < 16; ++r) {
+                vpart[t] += y[t][ob][r] * y[t][ob][r];
+                y[t][ob][r] = 2.f * y[t][ob][r];  // dV/dy
+            }
+        V[t] = vpart[t] + __shfl_xor(vpart[t], 32, 64) + p.eps_s * ee[t];
     }
+    if (!want_grad) return;
 
     // ---- backward 3: dH2' (128 x 32) = W3 (128 x 64) . (2 Y') -------------------------------------------
     f32x16 d2[TL][4];
     zero_acc(d2);
-    mfma_chain<OffW3B, 32, 4, 2, TL>(d2, ring4, c.w3b, [&](int st, int t) {
-        const float v = y[t][st >> 4][st & 15];
-        vpart[t] += v * v;
-        return 2.f * v;  // dV/dy
-    });
-#pragma unroll
-    for (int t = 0; t < TL; ++t) V[t] = vpart[t] + __shfl_xor(vpart[t], 32, 64) + p.eps_s * ee[t];
+    mfma_chain<OffW3B, 32, 4, 2, TL>(d2, ring4, c.w3b, [&](int st, int t) { return y[t][st >> 4][st & 15]; });
 
     // ---- backward 2: dH1' (128 x 32) = W2 . (dH2' . [h2 > 0]) -------------------------------------------
-    // (the pre-activations a2 are still in registers: compare + select per element, no mask words to build)
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[t][fb][r] = a2[t][fb][r] > 0.f ? d2[t][fb][r] : 0.f;
     f32x16 d1[TL][4];
     zero_acc(d1);
-    mfma_chain<OffW2B, 64, 4, 2, TL>(
-        d1, ring4, c.w2b, [&](int st, int t) { return a2[t][st >> 4][st & 15] > 0.f ? d2[t][st >> 4][st & 15] : 0.f; });
+    mfma_chain<OffW2B, 64, 4, 2, TL>(d1, ring4, c.w2b, [&](int st, int t) { return d2[t][st >> 4][st & 15]; });
 
     // ---- backward 1: dZ' (N x 32) = W1 (N x 128) . (dH1' . [h1 > 0]) on the VALU ---------------------------
     // Only N of an MFMA tile's 32 rows would be useful here (7.6 % of all MFMA time for n = 4); instead each
