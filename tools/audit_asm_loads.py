@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Audit of the inline-asm LDS prefetch in hjbx_mlp.hip (guide section 5.7, item 1): between an asm `ds_read_b32 vX`
-and the counted `s_waitcnt lgkmcnt(N)` that retires it, no compiler-generated instruction may touch vX (a copy
-or spill there would read the register before the data has landed).  Scans the device assembly of every kernel.
+"""Audit of the inline-asm LDS prefetch in hjbx_mlp.hip (guide section 5.7, item 1): between an asm `ds_read_b32 vX` /
+`ds_read_b64 v[X:Y]` / `ds_read_b128 v[X:Y]` and the counted `s_waitcnt lgkmcnt(N)` that retires it, no
+compiler-generated instruction may touch the destination register(s) (a copy or spill there would read them before the
+data has landed).  lgkmcnt counts instructions, so a wide read is one entry.  Scans the device assembly of every kernel.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -S --cuda-device-only -o /tmp/mlp.s csrc/hjbx_mlp.hip
     python tools/audit_asm_loads.py /tmp/mlp.s
@@ -38,11 +39,10 @@ def audit(path):
         if not s or s.startswith(";") or s.startswith("."):
             continue
         if in_asm:
-            m = re.match(r"ds_read_b32 v(\d+),", s)
+            m = re.match(r"ds_read_b(?:32|64|128) (v\d+|v\[\d+:\d+\]),", s)
             if m:
-                pending.append(int(m.group(1)))
+                pending.append(frozenset(regs_of(m.group(1))))
                 nreads += 1
-                continue
             continue
         if s.startswith("s_endpgm"):
             pending = []
@@ -53,11 +53,11 @@ def audit(path):
                 keep = int(m.group(1))
                 pending = pending[len(pending) - keep:] if keep else []
             continue
-        touched = regs_of(s.split(";")[0]) & set(pending)
+        touched = regs_of(s.split(";")[0]) & set().union(*pending)
         if touched:
             bad += 1
             print(f"{path}:{ln}: [{kernel[:50]}] compiler instruction touches pending asm-load register(s) {sorted(touched)}: {s}")
-    print(f"{nkern} functions, {nreads} asm ds_read_b32, {bad} violations")
+    print(f"{nkern} functions, {nreads} asm ds_read, {bad} violations")
     return bad
 
 
