@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 100 /* major*100 + minor */
+#define HJBX_VERSION 101 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -63,8 +63,18 @@ typedef enum hjbx_integrator {
 
 typedef enum hjbx_residual_mode {
     HJBX_RESIDUAL_NORMALISED = 0, /* |gradV.xdot/(l+eps) + 1| (1-done): controller/vhjb.py:233       */
-    HJBX_RESIDUAL_RAW = 1         /* |gradV.xdot + l| (1-done): examples/cartpole_balancing.ipynb cell 11 */
+    HJBX_RESIDUAL_RAW = 1         /* |gradV.xdot + l| (1-done): examples/cartpole_balancing.ipynb cell 11; with
+                                     HJBX_LAW_BANGBANG and done = 0 this is pd_hjb_loss of the time-optimal notebook (cell 11) */
 } hjbx_residual_mode;
+
+/* How u is obtained from gradV, and which running cost goes with it (hjbx_task.law). */
+typedef enum hjbx_control_law {
+    HJBX_LAW_QUADRATIC = 0, /* u = clip(-Rinv f2' gradV / 2 + uf), l = e'Qe + (u-uf)'R(u-uf): controller/vhjb.py:162-165, 218-220 */
+    HJBX_LAW_BANGBANG = 1   /* time-optimal learning (examples/double_integrator_optimal_time.ipynb cells 7, 9, 11):
+                               u_j = umax_j if (f2' gradV)_j < 0, umin_j if > 0, 0 if == 0  (= -sign(gradV @ B) for +-1 limits);
+                               l = 1 outside the target ball e'e > target_r2, 0 inside; rollouts end inside the ball
+                               (terminal tuple, cost e'Pe) as well as outside the observation box; d u / d gradV = 0 */
+} hjbx_control_law;
 
 typedef enum hjbx_controller_kind {
     HJBX_CTRL_LINEAR_FEEDBACK = 0, /* u = clip(-K e + uf): controller/lqr.py:25-26, quadrotors_model_based_controller.py:36-38, 73-75 */
@@ -96,6 +106,9 @@ typedef struct hjbx_task {
     double obs_min[HJBX_MAX_N]; /* bounds on the error coordinates wrap(x-xf), strict compares */
     double obs_max[HJBX_MAX_N];
     double eps;                 /* VHJBControllerConfig.epsilon */
+    int32_t law;                /* hjbx_control_law; 0 = the reference's VHJBController */
+    int32_t _pad;
+    double target_r2;           /* HJBX_LAW_BANGBANG: squared radius of the target ball ("metric", notebook cell 7) */
 } hjbx_task;
 
 /* Closed-form feedback laws. */

@@ -202,9 +202,18 @@ static REAL FN(quad_form)(int n, const double* A, const REAL* v) { /* v' A v */
     return acc;
 }
 
-/* VHJBController.running_cost, vhjb.py:162-165 */
+/* e'e <= target_r2: the "x.T @ x <= metric" test of the time-optimal notebook (cells 7, 9) */
+static int FN(in_target)(const orc_system* s, const hjbx_task* t, const REAL* x) {
+    REAL e[HJBX_MAX_N], n2 = 0;
+    FN(err1)(s, t->xf, x, e);
+    for (int i = 0; i < s->n; ++i) n2 += e[i] * e[i];
+    return n2 <= (REAL)t->target_r2;
+}
+
+/* VHJBController.running_cost, vhjb.py:162-165; HJBX_LAW_BANGBANG: np.where(norms > metric, 1, 0) (notebook cell 7) */
 static REAL FN(running_cost1)(const orc_system* s, const hjbx_task* t, const REAL* x, const REAL* u) {
     REAL e[HJBX_MAX_N], du[HJBX_MAX_M];
+    if (t->law == HJBX_LAW_BANGBANG) return FN(in_target)(s, t, x) ? (REAL)0 : (REAL)1;
     FN(err1)(s, t->xf, x, e);
     for (int j = 0; j < s->m; ++j) du[j] = u[j] - (REAL)t->uf[j];
     return FN(quad_form)(s->n, t->Q, e) + FN(quad_form)(s->m, t->R, du);
@@ -227,6 +236,13 @@ static void FN(control_from_grad1)(const orc_system* s, const hjbx_task* t, cons
         REAL acc = 0;
         for (int i = 0; i < n; ++i) acc += f2[i * m + j] * g[i];
         f2tg[j] = acc;
+    }
+    if (t->law == HJBX_LAW_BANGBANG) {
+        /* examples/double_integrator_optimal_time.ipynb cells 9, 11: u = -sign(gradV @ B) with |u| <= 1; for a general
+         * box the minimiser of gradV.f2 u: umax where (f2'g)_j < 0, umin where > 0, and sign(0) = 0 */
+        for (int j = 0; j < m; ++j)
+            u_raw[j] = u[j] = (f2tg[j] < 0) ? (REAL)s->umax[j] : ((f2tg[j] > 0) ? (REAL)s->umin[j] : (REAL)0);
+        return;
     }
     for (int j = 0; j < m; ++j) {
         REAL acc = 0;
@@ -258,7 +274,7 @@ static REAL FN(hjb_residual1)(const orc_system* s, const hjbx_task* t, int mode,
         /* du/dg = -1/2 D Rinv f2'  (m x n), D = 1 on unclipped controls */
         REAL dudg[HJBX_MAX_M * HJBX_MAX_N];
         for (int j = 0; j < m; ++j) {
-            const int open = (u_raw[j] > (REAL)s->umin[j]) && (u_raw[j] < (REAL)s->umax[j]);
+            const int open = t->law == HJBX_LAW_QUADRATIC && (u_raw[j] > (REAL)s->umin[j]) && (u_raw[j] < (REAL)s->umax[j]);
             for (int i = 0; i < n; ++i) {
                 REAL acc = 0;
                 for (int k = 0; k < m; ++k) acc += (REAL)t->Rinv[j * m + k] * f2[i * m + k];
@@ -514,7 +530,8 @@ void FN(orc_vhjb_step)(const orc_system* s, const hjbx_task* t, int integrator, 
         for (int j = 0; j < m; ++j) u[j] = 0;
         REAL c = 0, d = 0, res = 0;
         if (done_step[b] < 0) {
-            if (step >= T_max || FN(out_of_box)(s, t, xb)) {
+            const int reached = t->law == HJBX_LAW_BANGBANG && FN(in_target)(s, t, xb);
+            if (step >= T_max || reached || FN(out_of_box)(s, t, xb)) {
                 c = FN(termination_cost1)(s, t, xb); d = 1; done_step[b] = step;
             } else {
                 REAL f1[HJBX_MAX_N], f2[HJBX_MAX_N * HJBX_MAX_M], ur[HJBX_MAX_M];
@@ -562,7 +579,8 @@ int64_t FN(orc_vhjb_rollout)(const orc_system* s, const hjbx_task* t, const orc_
                 if (traj) for (int i = 0; i < n; ++i) traj[((int64_t)step * B + b) * n + i] = x[i];
                 REAL c = 0;
                 if (ds < 0) {
-                    if (step == T_max || FN(out_of_box)(s, t, x)) {
+                    const int reached = t->law == HJBX_LAW_BANGBANG && FN(in_target)(s, t, x);
+                    if (step == T_max || reached || FN(out_of_box)(s, t, x)) {
                         c = FN(termination_cost1)(s, t, x); ds = step;
                     } else {
                         FN(value_grad1)(s, p, W1, W2, W3, x, g, scratch);

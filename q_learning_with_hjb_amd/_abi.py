@@ -20,6 +20,7 @@ SYS_LINEAR, SYS_CARTPOLE, SYS_ACROBOT, SYS_QUAD2D, SYS_NEARHOVER = range(5)
 EULER, RK4, ZOH = 0, 1, 2
 RESIDUAL_NORMALISED, RESIDUAL_RAW = 0, 1
 CTRL_LINEAR_FEEDBACK, CTRL_CARTPOLE_ENERGY, CTRL_ACROBOT_ENERGY, CTRL_DI_TIME_OPTIMAL = 0, 1, 2, 3
+LAW_QUADRATIC, LAW_BANGBANG = 0, 1
 ROLLOUT_TERMINATE = 1
 ROLLOUT_STOP_AT_TARGET = 2
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
@@ -42,6 +43,9 @@ class HjbxTask(C.Structure):
         ("obs_min", C.c_double * HJBX_MAX_N),
         ("obs_max", C.c_double * HJBX_MAX_N),
         ("eps", C.c_double),
+        ("law", C.c_int32),
+        ("_pad", C.c_int32),
+        ("target_r2", C.c_double),
     ]
 
 
@@ -86,8 +90,9 @@ def _fill(dst, src):
         dst[i] = float(v)
 
 
-def make_task(n, m, Q, R, P, xf, uf, obs_min, obs_max, eps, Rinv=None) -> HjbxTask:
-    """Pack the task part of VHJBControllerConfig (+P) into struct hjbx_task."""
+def make_task(n, m, Q, R, P, xf, uf, obs_min, obs_max, eps, Rinv=None, law=0, target_r2=0.0) -> HjbxTask:
+    """Pack the task part of VHJBControllerConfig (+P) into struct hjbx_task.  law = LAW_BANGBANG selects the
+    time-optimal control law / unit running cost with the target ball e'e <= target_r2."""
     Q = np.asarray(Q, np.float64).reshape(n, n)
     R = np.asarray(R, np.float64).reshape(m, m)
     t = HjbxTask()
@@ -100,6 +105,8 @@ def make_task(n, m, Q, R, P, xf, uf, obs_min, obs_max, eps, Rinv=None) -> HjbxTa
     _fill(t.obs_min, np.full(n, -np.inf) if obs_min is None else np.asarray(obs_min, np.float64).reshape(n))
     _fill(t.obs_max, np.full(n, np.inf) if obs_max is None else np.asarray(obs_max, np.float64).reshape(n))
     t.eps = float(eps)
+    t.law = int(law)
+    t.target_r2 = float(target_r2)
     return t
 
 

@@ -41,11 +41,20 @@ def lecun_normal_(w: torch.Tensor, generator=None):
 class ValueFunctionApproximator(torch.nn.Module):
     """V(x) = ||MLP((e - mean)/std)||^2 + eps_s ||e||^2,  e = wrap(x - xf); bias-free Dense layers
     with ReLU between them so that V(xf) = 0 (reference vhjb.py:17-60).  Kernels are stored
-    (in, out) and applied as `x @ W`, like Flax."""
+    (in, out) and applied as `x @ W`, like Flax.  `activation` "sin" / "tanh" give the notebook variants
+    (examples/double_integrator_optimal_time.ipynb cell 5, examples/cartpole_balancing.ipynb): odd functions
+    with act(0) = 0, so V(xf) = 0 still holds; the fused MFMA kernel exists for "relu" only."""
+
+    _ACT = {"relu": (torch.relu, lambda a: (a > 0).to(a.dtype)),
+            "sin": (torch.sin, torch.cos),
+            "tanh": (torch.tanh, lambda a: 1.0 - torch.tanh(a) ** 2)}
 
     def __init__(self, dynamics: Dynamics, features: Sequence[int], mean, std, xf, epsilon_scalar: float,
-                 using_batch_norm: bool = False, dtype=torch.float32, device=None, generator=None):
+                 using_batch_norm: bool = False, dtype=torch.float32, device=None, generator=None, activation: str = "relu"):
         super().__init__()
+        if activation not in self._ACT:
+            raise ValueError(f"activation must be one of {sorted(self._ACT)}, got {activation!r}")
+        self.activation = activation
         if using_batch_norm:
             raise NotImplementedError("BatchNorm is disabled in every reference config and is not implemented")
         if len(features) != 3:
@@ -82,16 +91,17 @@ class ValueFunctionApproximator(torch.nn.Module):
         W1, W2, W3 = self.weights
         e = self.error_coords(x)
         z = (e - self.mean) / self.std
+        act, dact = self._ACT[self.activation]
         a1 = z @ W1
-        h1 = torch.relu(a1)
+        h1 = act(a1)
         a2 = h1 @ W2
-        h2 = torch.relu(a2)
+        h2 = act(a2)
         y = h2 @ W3
         V = (y * y).sum(-1) + self.epsilon_scalar * (e * e).sum(-1)
         if not want_grad:
             return V, None
-        d2 = ((2.0 * y) @ W3.t()) * (a2 > 0)
-        d1 = (d2 @ W2.t()) * (a1 > 0)
+        d2 = ((2.0 * y) @ W3.t()) * dact(a2)
+        d1 = (d2 @ W2.t()) * dact(a1)
         g = (d1 @ W1.t()) / self.std + (2.0 * self.epsilon_scalar) * e
         return V, g
 
@@ -130,6 +140,8 @@ class ValueFunctionApproximator(torch.nn.Module):
     @torch.no_grad()
     def fused_value_grad(self, x: torch.Tensor, want_v=True, want_grad=True):
         """Inference-only V and dV/dx from the fused MFMA kernel (float32)."""
+        if self.activation != "relu":
+            raise NotImplementedError("the fused value-gradient kernel implements the reference's ReLU network only")
         for w in self.weights:
             assert w.is_contiguous() and w.dtype == torch.float32
         return _ops.value_grad(self.dynamics.system, self.descriptor(), x, want_v, want_grad)

@@ -28,7 +28,17 @@ template <typename T, int N, int M> inline TaskP<T, N, M> make_task(const hjbx_t
     for (int i = 0; i < N; ++i) { k.xf[i] = (T)t->xf[i]; k.omin[i] = (T)t->obs_min[i]; k.omax[i] = (T)t->obs_max[i]; }
     for (int j = 0; j < M; ++j) k.uf[j] = (T)t->uf[j];
     k.eps = (T)t->eps;
+    k.target_r2 = (T)t->target_r2;
+    k.law = t->law;
     return k;
+}
+
+inline int check_task(const hjbx_task* t) {
+    if (!t) return hjbx_set_error(HJBX_EINVAL, "task is NULL");
+    if (t->law != HJBX_LAW_QUADRATIC && t->law != HJBX_LAW_BANGBANG) return hjbx_set_error(HJBX_EINVAL, "unknown control law %d", t->law);
+    if (t->law == HJBX_LAW_BANGBANG && !(t->target_r2 >= 0.0))
+        return hjbx_set_error(HJBX_EINVAL, "bang-bang law: target_r2 must be >= 0, got %g", t->target_r2);
+    return HJBX_OK;
 }
 
 template <typename T, int N, int M> inline CtrlP<T, N, M> make_ctrl(const hjbx_controller* c) {

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
 #pragma unroll
                 for (int k = 0; k < M; ++k) b += (tk.R[j * M + k] + tk.R[k * M + j]) * (u[k] - tk.uf[k]);
                 rdu[j] = b;
-                open[j] = (ur[j] > lim.umin[j]) && (ur[j] < lim.umax[j]);
+                open[j] = tk.law == 0 && (ur[j] > lim.umin[j]) && (ur[j] < lim.umax[j]);
             }
             const T sg = (r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0));
             T out[N];
@@ -494,7 +494,7 @@ static int initial_state_impl(const hjbx_system* sys, const double* mean, const 
 
 template <typename T>
 static int running_cost_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, const T* u, T* cost, int64_t B, void* st) {
-    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL"); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(cost, 1);
+    HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc; HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(cost, 1);
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             hipLaunchKernelGGL((k_running_cost<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
@@ -505,7 +505,7 @@ static int running_cost_impl(const hjbx_system* sys, const hjbx_task* task, cons
 
 template <typename T>
 static int termination_cost_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, T* cost, int64_t B, void* st) {
-    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL"); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(cost, 1);
+    HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc; HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(cost, 1);
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             hipLaunchKernelGGL((k_termination_cost<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
@@ -516,7 +516,7 @@ static int termination_cost_impl(const hjbx_system* sys, const hjbx_task* task, 
 
 template <typename T>
 static int control_from_grad_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, const T* g, T* u, int64_t B, void* st) {
-    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL"); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(u, sys->m);
+    HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc; HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(u, sys->m);
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             hipLaunchKernelGGL((k_control_from_grad<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
@@ -535,7 +535,7 @@ static int hjb_residual_impl(const hjbx_system* sys, const hjbx_task* task, int 
                              T* loss_i, T* dl_dg, T* sums, void* workspace, int64_t B, void* st) {
     HJBX_REQUIRE(sys != nullptr, "system handle is NULL");
     HJBX_REQUIRE(B >= 0, "negative batch size");
-    HJBX_REQUIRE(task, "task is NULL");
+    if (int rc = check_task(task)) return rc;
     HJBX_REQUIRE(mode == HJBX_RESIDUAL_NORMALISED || mode == HJBX_RESIDUAL_RAW, "unknown residual mode %d", mode);
     HJBX_REQUIRE(!sums || (workspace && aligned16(workspace)), "sums requested but workspace is NULL/unaligned");
     if (B == 0) {
@@ -587,7 +587,7 @@ static int termination_residual_impl(double eps, const T* V, const T* cost, cons
 template <typename T>
 static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int integ, int t, int T_max, const T* x, const T* g,
                           T* xn, T* u_out, T* cost_t, T* done_t, int32_t* done_step, T* resid_t, int64_t B, void* st) {
-    HJBX_CHECK_COMMON(sys, B); HJBX_REQUIRE(task, "task is NULL");
+    HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc;
     if (int rc = check_integrator(sys, integ, "hjbx_vhjb_step")) return rc;
     HJBX_REQUIRE(t >= 0 && T_max >= 0, "negative step index");
     HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(xn, sys->n); HJBX_CHECK_OPT(u_out, sys->m);
@@ -692,6 +692,7 @@ static int rollout_feedback_impl(const hjbx_system* sys, const hjbx_task* task, 
     HJBX_REQUIRE(T_steps >= 0, "negative horizon");
     HJBX_REQUIRE((flags & ~(HJBX_ROLLOUT_TERMINATE | HJBX_ROLLOUT_STOP_AT_TARGET)) == 0, "unknown rollout flags 0x%x", flags);
     HJBX_REQUIRE(task || !(flags & HJBX_ROLLOUT_TERMINATE), "HJBX_ROLLOUT_TERMINATE needs a task");
+    if (task) { if (int rc = check_task(task)) return rc; }
     HJBX_REQUIRE(task || (!cost && !total_cost), "cost outputs need a task");
     HJBX_CHECK_ROWS(x0, sys->n); HJBX_CHECK_OPT(traj, sys->n); HJBX_CHECK_OPT(u_log, sys->m); HJBX_CHECK_OPT(x_final, sys->n);
     if (!with_system<T>(sys, [&](auto S) {

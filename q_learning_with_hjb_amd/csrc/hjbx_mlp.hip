@@ -609,6 +609,7 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
                                      int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
                                      float* resid, int32_t* done_step, float* x_out, int64_t B, void* stream) {
     if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: NULL system, task or mlp descriptor");
+    if (int rc = check_task(task)) return rc;
     if (B < 0 || n_steps < 0 || t_first < 0 || T_max < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: negative size or step index");
     if (int rc = check_integrator(sys, integrator, "hjbx_vhjb_rollout_f32")) return rc;
     if (B == 0) return HJBX_OK;

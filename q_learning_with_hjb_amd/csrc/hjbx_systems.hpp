@@ -245,6 +245,8 @@ template <typename T, int M> struct Limits { T umin[M], umax[M], dt; };
 
 template <typename T, int N, int M> struct TaskP {
     T Q[N * N], R[M * M], Rinv[M * M], P[N * N], xf[N], uf[M], omin[N], omax[N], eps;
+    T target_r2;  // HJBX_LAW_BANGBANG: squared radius of the target ball
+    int law;      // hjbx_control_law
 };
 
 template <typename T, int N, int M> struct CtrlP {
@@ -307,7 +309,8 @@ template <int N, typename T> HJBX_DEV T quad_form(const T* A, const T* v) {
     return acc;
 }
 
-// vhjb.py:220: u_raw = -Rinv f2' g / 2 + uf ; u = clip(u_raw)
+// vhjb.py:220: u_raw = -Rinv f2' g / 2 + uf ; u = clip(u_raw).  HJBX_LAW_BANGBANG (time-optimal notebook, cells 9 and 11:
+// u = -sign(gradV @ B)): u_j = umax_j / umin_j / 0 by the sign of (f2' g)_j; u_raw = u (nothing is "open": du/dg = 0).
 template <typename S, typename T>
 HJBX_DEV void control_from_grad(const TaskP<T, S::N, S::M>& tk, const Limits<T, S::M>& lim, const T* f2, const T* g,
                                 T* u_raw, T* u) {
@@ -320,6 +323,11 @@ HJBX_DEV void control_from_grad(const TaskP<T, S::N, S::M>& tk, const Limits<T, 
         for (int i = 0; i < N; ++i) acc += f2[i * M + j] * g[i];
         f2tg[j] = acc;
     }
+    if (tk.law != 0) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) u_raw[j] = u[j] = (f2tg[j] < T(0)) ? lim.umax[j] : ((f2tg[j] > T(0)) ? lim.umin[j] : T(0));
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         T acc = T(0);
@@ -330,9 +338,17 @@ HJBX_DEV void control_from_grad(const TaskP<T, S::N, S::M>& tk, const Limits<T, 
     clip_u<T, M>(lim, u_raw, u);
 }
 
-// running cost given the error coordinates: e'Qe + (u-uf)'R(u-uf)   (vhjb.py:162-165)
+// running cost given the error coordinates: e'Qe + (u-uf)'R(u-uf)   (vhjb.py:162-165); HJBX_LAW_BANGBANG: 1 outside the
+// target ball, 0 inside (np.where(norms > metric, 1, 0), time-optimal notebook cell 7)
+template <typename S, typename T> HJBX_DEV T norm2_e(const T* e) {
+    T s = T(0);
+#pragma unroll
+    for (int i = 0; i < S::N; ++i) s += e[i] * e[i];
+    return s;
+}
 template <typename S, typename T>
 HJBX_DEV T running_cost_e(const TaskP<T, S::N, S::M>& tk, const T* e, const T* u) {
+    if (tk.law != 0) return (norm2_e<S, T>(e) > tk.target_r2) ? T(1) : T(0);
     T du[S::M];
 #pragma unroll
     for (int j = 0; j < S::M; ++j) du[j] = u[j] - tk.uf[j];
@@ -366,7 +382,8 @@ HJBX_DEV void vhjb_step_env(const S& sys, const TaskP<T, S::N, S::M>& tk, const 
     if (ds < 0) {
         T e[N];
         error_coords(sys, tk.xf, xs, e);
-        if (t >= T_max || out_of_box<S, T>(tk, e)) {  // vhjb.py:176-181 and 188-191
+        const bool reached = tk.law != 0 && norm2_e<S, T>(e) <= tk.target_r2;  // time-optimal notebook cell 9: x'x <= metric
+        if (t >= T_max || reached || out_of_box<S, T>(tk, e)) {  // vhjb.py:176-181 and 188-191
             c = quad_form<N>(tk.P, e);
             d = T(1);
             ds = t;

@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     L = _abi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), f"libhjbx.so does not export {name}"
-    assert L.hjbx_version() == 100
+    assert L.hjbx_version() == 101
     assert L.hjbx_reduce_workspace_bytes() >= 3 * 8
 
 
@@ -33,7 +33,7 @@ def test_descriptor_layouts_match_the_header():
     """ctypes structs == the C structs of include/hjbx.h (sizes checked against a gcc build of the header)."""
     from oracle import oracle as O
     O.lib()  # runs check_layout()
-    assert C.sizeof(_abi.HjbxTask) == 8 * (100 + 9 + 9 + 100 + 10 + 3 + 10 + 10 + 1)
+    assert C.sizeof(_abi.HjbxTask) == 8 * (100 + 9 + 9 + 100 + 10 + 3 + 10 + 10 + 1 + 1 + 1)
 
 
 def test_system_create_errors_map_to_python_exceptions():

@@ -172,3 +172,82 @@ def test_time_optimal_double_integrator_vs_reference_ground_truth():
     lqr = _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, 2, 1, Bm.T @ Pl, wrap_error=False, eps_region=1e-4)
     t_lqr = O.rollout_feedback(s, lqr, x0, 1500, integrator=_abi.ZOH, stop_at_target=True, log=False)["done_step"] * 0.01
     assert t_reach.mean() < 0.5 * t_lqr.mean()
+
+
+def _min_time_value_and_grad(p, v):
+    """Closed-form minimum time to the origin of the double integrator with |u| <= 1 and its gradient:
+    right of the switching curve p = -v|v|/2 (first arc u = -1): T = v + 2 sqrt(v^2/2 + p); left of it (u = +1):
+    T = -v + 2 sqrt(v^2/2 - p)."""
+    right = p > -0.5 * v * np.abs(v)
+    s = np.where(right, 0.5 * v * v + p, 0.5 * v * v - p)
+    rs = np.sqrt(np.maximum(s, 1e-300))
+    T = np.where(right, v, -v) + 2 * rs
+    dTdp = np.where(right, 1.0, -1.0) / rs
+    dTdv = np.where(right, 1.0, -1.0) + v / rs
+    return T, np.stack([dTdp, dTdv], -1), right
+
+
+def test_bang_bang_law_known_answer_minimum_time_value_function():
+    """HJBX_LAW_BANGBANG (u = -sign(gradV @ B), unit running cost; time-optimal notebook cells 7, 9, 11) fed with the
+    gradient of the analytic minimum-time function T: the law must return the analytic bang-bang control
+    (notebook cell 18's get_analytical_control = HJBX_CTRL_DI_TIME_OPTIMAL) and the raw HJB residual
+    gradT . (Ax + Bu) + 1 must vanish.  T itself is pinned to `attr`, the analytic solution stored in the reference's .mat."""
+    g = load_golden("di_time_optimal")
+    P, V = np.meshgrid(g["pos"], g["vel"], indexing="ij")
+    T, grad, right = _min_time_value_and_grad(P, V)
+    # same function as the reference's ground truth: `attr` is T less a constant 0.01 (clipped at the origin node), so the
+    # gradients coincide
+    assert np.abs(np.maximum(T - 0.01, 0.0) - g["attr"]).max() < 1e-6
+    d = _double_integrator()
+    s = O.System.from_dynamics(d)
+    x = np.stack([P.ravel(), V.ravel()], 1)
+    gr = grad.reshape(-1, 2)
+    margin = np.abs(P + 0.5 * V * np.abs(V)).ravel() > 1e-3                 # off the switching curve (gradT jumps across it)
+    outside = (x * x).sum(1) > 1e-4
+    keep = margin & outside
+    task = _abi.make_task(2, 1, np.eye(2), np.eye(1), None, [0, 0], [0], None, None, 0.0, law=_abi.LAW_BANGBANG, target_r2=1e-4)
+    u = O.control_from_grad(s, task, x, gr)
+    ctrl = _abi.make_controller(_abi.CTRL_DI_TIME_OPTIMAL, 2, 1, np.zeros((1, 2)), wrap_error=False, eps_region=1e-4)
+    u_ref = O.controller(s, ctrl, x)
+    assert np.array_equal(u[keep], u_ref[keep])
+    assert set(np.unique(u[keep])) == {-1.0, 1.0}
+    li, dg, sums = O.hjb_residual(s, task, x, gr, np.zeros(len(x)), mode=_abi.RESIDUAL_RAW)
+    assert np.abs(li[keep]).max() < 1e-9                                    # gradT . xdot + 1 = 0 (HJB of the min-time problem)
+    assert sums[1] == len(x) and sums[2] == 0
+    # d loss / d gradV = sign(r) xdot: the control is piecewise constant in gradV
+    xd = O.dynamics_step(s, x, u)
+    g2 = gr + 0.3                                                           # off the solution so that r != 0
+    li2, dg2, _ = O.hjb_residual(s, task, x, g2, np.zeros(len(x)), mode=_abi.RESIDUAL_RAW)
+    u2 = O.control_from_grad(s, task, x, g2)
+    xd2 = O.dynamics_step(s, x, u2)
+    r2 = (g2 * xd2).sum(1) + outside
+    close(li2, np.abs(r2), rtol=1e-12, atol=1e-12)
+    close(dg2, np.sign(r2)[:, None] * xd2, rtol=1e-12, atol=1e-12)
+    # running cost of the law: 1 outside the target ball, 0 inside
+    assert np.array_equal(O.running_cost(s, task, x, u), outside.astype(np.float64))
+    del xd
+
+
+def test_bang_bang_rollout_stops_in_the_target_ball_and_counts_time():
+    """vhjb_step with HJBX_LAW_BANGBANG: stepping with gradT reproduces the analytic controller's closed loop
+    (done_step x dt = time to origin), each live step costs dt, the terminal tuple costs e'Pe = 0."""
+    d = _double_integrator()
+    s = O.System.from_dynamics(d)
+    rng = np.random.default_rng(1)
+    x0 = rng.uniform(-1, 1, (64, 2))
+    task = _abi.make_task(2, 1, np.eye(2), np.eye(1), None, [0, 0], [0], None, None, 0.0, law=_abi.LAW_BANGBANG, target_r2=1e-4)
+    T_max = 600
+    x, ds = x0.copy(), np.full(64, -1, np.int32)
+    total = np.zeros(64)
+    for t in range(T_max + 1):
+        _, grad, _ = _min_time_value_and_grad(x[:, 0], x[:, 1])
+        x, _, c, _, ds, _ = O.vhjb_step(s, task, t, T_max, x, grad, ds, integrator=_abi.ZOH)
+        total += c
+        if (ds >= 0).all():
+            break
+    ctrl = _abi.make_controller(_abi.CTRL_DI_TIME_OPTIMAL, 2, 1, np.zeros((1, 2)), wrap_error=False, eps_region=1e-4)
+    ref = O.rollout_feedback(s, ctrl, x0, T_max, integrator=_abi.ZOH, stop_at_target=True, log=False)
+    assert (ds >= 0).all() and ds.max() < T_max
+    # the two laws differ only on the switching curve itself (measure zero until chatter puts states next to it)
+    assert np.abs(ds - ref["done_step"]).max() <= 30 and np.median(np.abs(ds - ref["done_step"])) <= 2
+    close(total, ds * 0.01, rtol=1e-12, atol=1e-12)
