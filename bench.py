@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1 << 20, help="environments per GPU")
-    ap.add_argument("--system", default="cartpole", choices=["cartpole", "quad2d", "nearhover", "linear"],
+    ap.add_argument("--system", default="cartpole", choices=["cartpole", "acrobot", "quad2d", "nearhover", "linear"],
                     help="default cartpole = BASELINE configs[1]; quad2d / nearhover = the VHJB loops of configs[3] / configs[4]")
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"], help="euler = the reference's integrator (parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,6 +78,7 @@ def main():
     from q_learning_with_hjb_amd import _abi, _ops
     from q_learning_with_hjb_amd.configs import defaults as D
     from q_learning_with_hjb_amd.controller.vhjb import VHJBController
+    from q_learning_with_hjb_amd.dynamics.acrobot import Acrobot
     from q_learning_with_hjb_amd.dynamics.cartpole import Cartpole
     from q_learning_with_hjb_amd.dynamics.linear import LinearDynamics
     from q_learning_with_hjb_amd.dynamics.quadrotors import NearHoverQuadcopter, Quadrotors2D
@@ -85,6 +86,8 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     dyn, ccfg, label = {
         "cartpole": lambda: (Cartpole(D.cartpole_dynamics_config()), D.cartpole_vhjb_config(), "cartpole balancing + vhjb controller (BASELINE configs[1])"),
+        "acrobot": lambda: (Acrobot(D.acrobot_dynamics_config(x0_mean=[np.pi, 0, 0, 0], x0_std=[0.5, 0.5, 1, 1])), D.acrobot_vhjb_config(),
+                            "acrobot at the upright + vhjb controller (BASELINE configs[2], closed-loop part)"),
         "quad2d": lambda: (Quadrotors2D(D.quadrotors2d_dynamics_config()), D.quadrotors2d_vhjb_config(), "Quadrotors2D hovering + vhjb controller (BASELINE configs[3])"),
         "nearhover": lambda: (NearHoverQuadcopter(D.near_hover_dynamics_config()), D.near_hover_vhjb_config(), "10-D near-hover quadcopter + vhjb controller (BASELINE configs[4])"),
         "linear": lambda: (LinearDynamics(D.linear_dynamics_config()), D.linear_vhjb_config(), "double integrator + vhjb controller"),

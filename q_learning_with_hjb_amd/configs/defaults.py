@@ -70,6 +70,19 @@ def cartpole_vhjb_config(**kw):  # configs/controller/cartpole_vhjb_controller.g
     return VHJBControllerConfig(**d)
 
 
+def acrobot_vhjb_config(**kw):
+    """Acrobot swing-up + balance at the upright (BASELINE configs[2]).  The reference ships NO acrobot VHJB config
+    (dynamics/acrobot.py is stale upstream): the cartpole file's hyper-parameters, the cost of the energy-shaping demo
+    (controller/acrobot_energy_shaping.py:13, Q = I, R = 1), target [pi, 0, 0, 0]; the observation box never cuts the wrapped
+    angles (|e| <= pi), so a swing-up from the hanging position stays live, and bounds the rates."""
+    d = _vhjb_common(4)
+    d.update(Q=np.eye(4).tolist(), R=[[1.0]], xf=[float(np.pi), 0, 0, 0], uf=[0], obs_min=[-4, -4, -30, -30], obs_max=[4, 4, 30, 30],
+             interior_states_mean=[float(np.pi), 0, 0, 0], interior_states_std=[0.5, 0.5, 2, 2],
+             boundary_states_mean=[float(np.pi), 0, 0, 0], boundary_states_std=[0.5, 0.5, 2, 2])
+    d.update(kw)
+    return VHJBControllerConfig(**d)
+
+
 def quadrotors2d_vhjb_config(**kw):  # configs/controller/quadrotors2DHovering_vhjb_controller.gin
     d = _vhjb_common(6)
     d.update(interior_states_mean=[0] * 6, interior_states_std=[1] * 6, boundary_states_mean=[0] * 6,

@@ -395,6 +395,34 @@ class VHJBController(Controller):
                            resid_t=(resid[t] if log_residual else None))
         return dict(traj=traj[:T + 1], cost=cost, done=done, done_step=done_step, u=ulog, residual=resid)
 
+    @torch.no_grad()
+    def warm_start(self, controller, num_of_trajectories: int, max_steps: Optional[int] = None, x0=None):
+        """Seed the replay buffer with closed loops of a model-based controller instead of the (untrained) learned
+        policy -- BASELINE configs[2] "energy-shaping warm-start + vhjb".  New behaviour: the reference has the
+        controllers (controller/acrobot_energy_shaping.py:74-121, cartpole_energy_shaping.py:65-110) and the buffer
+        (vhjb.py:62-73, 308) but no code joining them.  `controller` is any DeviceFeedbackController; its rollout runs in
+        the fused hjbx_rollout_feedback kernel under this controller's task with rollout_trajectory's termination
+        rules (observation box, forced terminal tuple at `max_steps`), and every emitted (x, cost, done) tuple is
+        appended trajectory by trajectory, exactly as `train` appends its own rollouts.
+        Returns dict(records, average_trajectory_cost, average_trajectory_length, done_step)."""
+        T = self.maximum_timestep if max_steps is None else int(max_steps)
+        if x0 is None:
+            x0 = self.dynamics.get_initial_state(batch_size=int(num_of_trajectories))
+        x0 = self._dev(np.atleast_2d(x0) if isinstance(x0, np.ndarray) else x0).contiguous()
+        B = x0.shape[0]
+        out = _ops.rollout_feedback(self.dynamics.system, controller._descriptor(), x0, T, task=self._task,
+                                    integrator=self.dynamics.integrator, terminate=True, log_traj=True, log_u=False, log_cost=True)
+        ds = out["done_step"].long()
+        steps = torch.arange(T + 1, device=self.device)[:, None]
+        valid = steps <= ds[None, :]                                  # (T+1, B): tuples up to and including the terminal one
+        done = (steps == ds[None, :]).to(self.dtype)
+        vm = valid.t().reshape(-1)
+        self.replay_buffer.extend(out["traj"].transpose(0, 1).reshape(-1, self.state_dim)[vm], out["cost"].t().reshape(-1)[vm],
+                                  done.t().reshape(-1)[vm])
+        costs = (out["cost"] * valid).sum(0)
+        return dict(records=int(vm.sum().item()), average_trajectory_cost=float(costs.mean().item()),
+                    average_trajectory_length=float((ds + 1).double().mean().item()), done_step=out["done_step"])
+
     def rollout_trajectory(self) -> List[Tuple[np.ndarray, float, float]]:
         """One trajectory as the reference returns it: a list of (x, cost, done) tuples."""
         x0 = self._dev(self.dynamics.get_initial_state(batch_size=1))

@@ -17,8 +17,10 @@ import torch
 from .. import _abi, _ops
 from ..configs import defaults, gin_lite
 from ..configs.controller.vhjb_controller_config import VHJBControllerConfig
-from ..configs.dynamics.dynamics_config import (CartpoleDynamicsConfig, LinearDynamicsConfig, NearHoverQuadcopterConfig,
-                                                Quadrotors2DConfig)
+from ..configs.dynamics.dynamics_config import (AcrobotDynamicsConfig, CartpoleDynamicsConfig, LinearDynamicsConfig,
+                                                NearHoverQuadcopterConfig, Quadrotors2DConfig)
+from ..controller.acrobot_energy_shaping import AcrobotEnergyShapingController
+from ..dynamics.acrobot import Acrobot
 from ..controller.cartpole_energy_shaping import CartpoleEnergyShapingController
 from ..controller.lqr import LQR
 from ..controller.quadrotors_model_based_controller import (NearHoverQuadcopterHoveringController,
@@ -32,6 +34,7 @@ _ENVS = {
     # name: (dynamics config class, stock dynamics config, dynamics class, stock controller config)
     "lqr": (LinearDynamicsConfig, defaults.linear_dynamics_config, LinearDynamics, defaults.linear_vhjb_config),
     "cartpole": (CartpoleDynamicsConfig, defaults.cartpole_dynamics_config, Cartpole, defaults.cartpole_vhjb_config),
+    "acrobot": (AcrobotDynamicsConfig, defaults.acrobot_dynamics_config, Acrobot, defaults.acrobot_vhjb_config),  # no upstream config
     "quadrotors2DHovering": (Quadrotors2DConfig, defaults.quadrotors2d_dynamics_config, Quadrotors2D, defaults.quadrotors2d_vhjb_config),
     "nearHoverQuadcopter": (NearHoverQuadcopterConfig, defaults.near_hover_dynamics_config, NearHoverQuadcopter,
                             defaults.near_hover_vhjb_config),   # notebook-only upstream (examples/10D_quadcopte.ipynb)
@@ -58,6 +61,8 @@ def load_systems(env_name, dynamics_config=None, vhjb_controller_config=None, **
         model_based = LQR(dynamics, Q, R)
     elif env_name == "cartpole":
         model_based = CartpoleEnergyShapingController(dynamics, Q, R)
+    elif env_name == "acrobot":
+        model_based = AcrobotEnergyShapingController(dynamics, Q, R)
     elif env_name == "quadrotors2DHovering":
         model_based = Quadrotors2DHoveringController(dynamics, np.asarray(ccfg.xf, np.float64), Q, R)
     else:
@@ -105,9 +110,13 @@ def main(argv=None):
     parser.add_argument("--epochs", type=int, default=None, help="override VHJBControllerConfig.epochs")
     parser.add_argument("--eval_batch", type=int, default=10, help="number of evaluation start states")
     parser.add_argument("--T", type=float, default=5.0)
+    parser.add_argument("--warm_start", type=int, default=0, help="seed the replay buffer with this many closed loops of the "
+                        "model-based controller before training (BASELINE configs[2]: energy-shaping warm-start + vhjb)")
     args = parser.parse_args(argv)
     over = {} if args.epochs is None else {"epochs": args.epochs}
     dynamics, nn_policy, model_based_policy = load_systems(args.env_name, args.dynamics_config, args.vhjb_controller_config, **over)
+    if args.warm_start > 0:
+        nn_policy.warm_start(model_based_policy, args.warm_start)
     lists = nn_policy.train()
     res = test_policy(nn_policy, dynamics, model_based_policy, T=args.T, batch=args.eval_batch)
     summary = dict(env=args.env_name, epochs=nn_policy.epochs,

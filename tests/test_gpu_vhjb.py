@@ -336,3 +336,39 @@ def test_cli_main_smoke(capsys):
     import json
     s = json.loads(out)
     assert s["env"] == "lqr" and s["epochs"] == 3 and len(lists) == 6 and res["xs_learned"].shape[1] == 4
+
+
+def test_warm_start_from_energy_shaping_fills_the_replay_buffer():
+    """BASELINE configs[2] (acrobot swing-up: energy-shaping warm-start + vhjb; new behaviour, no reference code): closed loops
+    of the acrobot energy-shaping controller from the hanging position, run by the fused rollout kernel under the VHJB task,
+    land in the replay buffer as the (x, cost, done) tuples rollout_trajectory would emit -- checked against the oracle."""
+    from q_learning_with_hjb_amd.configs import defaults as D
+    from q_learning_with_hjb_amd.controller.acrobot_energy_shaping import AcrobotEnergyShapingController
+    from q_learning_with_hjb_amd.dynamics.acrobot import Acrobot
+    d = Acrobot(D.acrobot_dynamics_config())
+    ctl = VHJBController(d, D.acrobot_vhjb_config(maximum_step=120), dtype=torch.float64)
+    es = AcrobotEnergyShapingController(d)
+    n0 = len(ctl.replay_buffer)
+    rng = np.random.default_rng(0)
+    x0 = np.array([0.001, 0, 0, 0]) + rng.uniform(-0.05, 0.05, (16, 4))
+    x0[3] = [0.3, 0.2, 31.0, 0.0]                                # outside the rate box: terminal tuple at step 0
+    info = ctl.warm_start(es, 16, x0=x0)
+    ds = info["done_step"].cpu().numpy()
+    assert ds[3] == 0 and (np.delete(ds, 3) == 120).all()       # the swing-up never leaves the box; forced terminal at T
+    assert info["records"] == int((ds + 1).sum()) and len(ctl.replay_buffer) == n0 + info["records"]
+    ref = O.rollout_feedback(O.System.from_dynamics(d), es._descriptor(), x0, 120, task=ctl._task, terminate=True)
+    assert np.array_equal(ref["done_step"], ds)
+    # trajectory-major order: env 0's 121 tuples first
+    rb = ctl.replay_buffer
+    xs = rb.x[n0:n0 + 121].cpu().numpy(); cs = rb.cost[n0:n0 + 121].cpu().numpy(); dn = rb.done[n0:n0 + 121].cpu().numpy()
+    assert np.abs(wrapped_diff(xs, ref["traj"][:, 0], [0, 1])).max() < 1e-8
+    assert np.abs(cs - ref["cost"][:, 0]).max() < 1e-8 * max(1.0, np.abs(ref["cost"][:, 0]).max())
+    assert dn[:-1].sum() == 0 and dn[-1] == 1
+    assert abs(info["average_trajectory_length"] - (ds + 1).mean()) < 1e-12
+    # the energy really is pumped up during the warm-start rollouts (a swing-up, not a stall at the bottom)
+    E = O.manip(O.System.from_dynamics(d), ref["traj"][:, 0])[3]
+    assert E.max() > E[0] + 5
+    # and training proceeds from the warm-started buffer
+    ctl.epochs, ctl.num_of_trajectories_per_epoch = 1, 4
+    lists = ctl.train()
+    assert len(lists[4]) == 1 and np.isfinite(lists[4][0])
