@@ -242,7 +242,7 @@ def main():
                            live_fraction=live / (B * world * K), parallelism=f"env-shard x{world}, no data-path collective"),
                roofline=roofline, kernels=other)
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the host-core baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(dyn, ctl, x0, args.cpu_sample_envs)
     if rank == 0:
         print(json.dumps(out))
