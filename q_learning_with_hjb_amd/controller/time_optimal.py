@@ -3,6 +3,7 @@ p = -v|v| / (2 umax), zero inside the target ball -- `get_analytical_control` of
 examples/double_integrator_optimal_time.ipynb (cell 18), used there as ground truth next to the level-set solution.
 Runs in the `hjbx_controller` / `hjbx_rollout_feedback` kernels like the other closed-form laws."""
 import numpy as np
+import torch
 
 from .. import _abi
 from .controller_basic import Controller
@@ -71,7 +72,10 @@ class TimeOptimalVHJBController(Controller):
             dynamics, features, np.zeros(n), np.ones(n), self.xf, epsilon_scalar, dtype=self.dtype, device=self.device,
             generator=self._gen, activation=activation)
         self.fused = activation == "relu" and self.dtype == torch.float32 and tuple(features) == (128, 128, 64)
-        self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8)
+        self.graph_updates = self.device.type == "cuda"   # optimiser steps of `train` replay from a hipGraph
+        self._graphed = None
+        self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8,
+                                          capturable=self.graph_updates)
         self.batch_size = int(batch_size)
         hw = torch.as_tensor(np.broadcast_to(np.asarray(state_halfwidth, np.float64), (n,)).copy(), dtype=self.dtype, device=self.device)
         self._halfwidth = hw
@@ -139,20 +143,34 @@ class TimeOptimalVHJBController(Controller):
         return float(tt.mean()), float(tt.std(unbiased=False))
 
     # -- learning ----------------------------------------------------------------------------------------
-    def hjb_loss(self, xs):
+    def hjb_loss(self, xs, weights=None):
         from .vhjb import _HJBResidualSum
-        _, g = self.value_function_approximator.value_and_grad(xs)
+        _, g = self.value_function_approximator.value_and_grad(xs, weights=weights)
         if self._zeros.shape[0] < xs.shape[0]:
             self._zeros = self._zeros.new_zeros(xs.shape[0])
         s, _ = _HJBResidualSum.apply(g, xs, self._zeros[:xs.shape[0]], self.dynamics.system, self._task, _abi.RESIDUAL_RAW)
         return s / xs.shape[0]
 
     def params_update(self, xs):
-        self.optimizer.zero_grad(set_to_none=True)
-        loss = self.hjb_loss(xs)
-        loss.backward()
+        # differentiate w.r.t. fresh leaves aliasing the parameters (see VHJBController._update_core): a hipGraph capture of
+        # this step must not meet grad accumulators that an older, still-alive autograd graph created on another stream
+        params = list(self.value_function_approximator.parameters())
+        leaves = [p.detach().requires_grad_(True) for p in params]
+        loss = self.hjb_loss(xs, weights=leaves)
+        for p, g in zip(params, torch.autograd.grad(loss, leaves)):
+            p.grad = g
         self.optimizer.step()
         return loss.detach()
+
+    def params_update_graphed(self, xs):
+        """`params_update` replayed from a hipGraph (captured for the full minibatch shape; a ragged last batch runs eagerly).
+        The returned loss is the graph's static output: consume it before the next call."""
+        from .vhjb import GraphedStep
+        if xs.shape[0] != self.batch_size:
+            return self.params_update(xs)
+        if self._graphed is None:
+            self._graphed = GraphedStep(self.optimizer, list(self.value_function_approximator.parameters()), self.params_update, (xs,))
+        return self._graphed(xs)
 
     def train(self, epochs: int = 100, evaluate: bool = True, verbose: bool = False):
         """-> (losses per epoch, mean time-to-target per epoch, std per epoch), as cell 11 collects them."""
@@ -167,7 +185,8 @@ class TimeOptimalVHJBController(Controller):
             perm = torch.randperm(N, generator=self._gen, device=self.device)
             total, nb = torch.zeros((), dtype=self.dtype, device=self.device), 0
             for i in range(0, N, self.batch_size):
-                total += self.params_update(self.states[perm[i:i + self.batch_size]].contiguous())
+                update = self.params_update_graphed if self.graph_updates else self.params_update
+                total += update(self.states[perm[i:i + self.batch_size]].contiguous())
                 nb += 1
             losses.append(float(total / max(nb, 1)))
             if verbose and (epoch + 1) % 10 == 0:

@@ -13,6 +13,7 @@ in lock-step, state resident in HBM, time-major logs `(T+1, B, ...)`.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -82,13 +83,14 @@ class ValueFunctionApproximator(torch.nn.Module):
         V, _ = self.value_and_grad(x, want_grad=False)
         return V
 
-    def value_and_grad(self, x: torch.Tensor, want_grad: bool = True):
-        """V (B,) and dV/dx (B, n) as differentiable functions of the weights.
+    def value_and_grad(self, x: torch.Tensor, want_grad: bool = True, weights=None):
+        """V (B,) and dV/dx (B, n) as differentiable functions of the weights (`weights`: stand-ins for the three
+        parameters, e.g. detached views that act as fresh autograd leaves).
 
         The input gradient is written out as reverse mode by hand (three transposed matmuls with the
         ReLU masks), which keeps d(grad)/d(weights) a plain first-order autograd graph -- the
         "double back-prop" of vhjb.py:282 without create_graph."""
-        W1, W2, W3 = self.weights
+        W1, W2, W3 = self.weights if weights is None else weights
         e = self.error_coords(x)
         z = (e - self.mean) / self.std
         act, dact = self._ACT[self.activation]
@@ -243,7 +245,8 @@ class ReplayBuffer:
 class VHJBController(Controller):
 
     def __init__(self, dynamics: Dynamics, config, device=None, dtype=torch.float32, process_group=None,
-                 residual_mode=_abi.RESIDUAL_NORMALISED, fused_value_grad: Optional[bool] = None) -> None:
+                 residual_mode=_abi.RESIDUAL_NORMALISED, fused_value_grad: Optional[bool] = None,
+                 graph_updates: Optional[bool] = None) -> None:
         super().__init__()
         self.device = torch.device(device) if device is not None else _ops.require_device()
         self.dtype = dtype
@@ -280,7 +283,15 @@ class VHJBController(Controller):
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen)
         self.fused_value_grad = (dtype == torch.float32) if fused_value_grad is None else bool(fused_value_grad)
         self.train_mode = False
-        self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=config.lr, betas=(0.9, 0.999), eps=1e-8)
+        # the optimiser step of `train` is replayed from a hipGraph (about 100 launch-bound kernels at batch 256); the
+        # data-parallel path keeps eager launches around its all-reduce
+        if graph_updates is None:   # HJBX_GRAPH_UPDATES=0 forces eager launches (debugging aid)
+            graph_updates = self.device.type == "cuda" and not self._distributed() and os.environ.get("HJBX_GRAPH_UPDATES", "1") != "0"
+        self.graph_updates = bool(graph_updates)
+        self._graphed_update = None
+        self._reg_buf = None
+        self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=config.lr, betas=(0.9, 0.999), eps=1e-8,
+                                          capturable=self.graph_updates and self.device.type == "cuda")
         self._sched = dict(init_value=config.regularization_init_value, peak_value=config.regularization_peak_value,
                            end_value=config.regularization_end_value, warmup_steps=config.regularization_warmup_steps_per_cycle,
                            decay_steps=config.regularization_total_steps_per_cycle, num_cycles=config.regularization_num_of_cycles)
@@ -464,19 +475,49 @@ class VHJBController(Controller):
         Data parallel: every rank contributes the gradient of its loss SUMS and its counts through
         ONE flat all-reduce; the division by the global counts happens afterwards, so the result equals
         the single-process update on the concatenated minibatch.  Returns (total, hjb, termination) losses."""
-        xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
+        return self._update_core(self._dev(xs), self._dev(dones), self._dev(costs), regularization)
+
+    def _update_core(self, xs, dones, costs, regularization):
+        """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph."""
         params = list(self.value_function_approximator.parameters())
-        V, g = self.value_function_approximator.value_and_grad(xs)
+        # differentiate w.r.t. fresh leaves that alias the parameters: their grad accumulators are created on the stream this
+        # step runs on, so a hipGraph capture cannot be joined to the stream of an older, still-alive autograd graph of the
+        # same parameters (that unjoined cross-stream wait crashes hipStreamEndCapture)
+        leaves = [p.detach().requires_grad_(True) for p in params]
+        V, g = self.value_function_approximator.value_and_grad(xs, weights=leaves)
         h_sum, h_sums = _HJBResidualSum.apply(g, xs, dones, self.dynamics.system, self._task, self.residual_mode)
         t_sum, _ = _TerminationResidualSum.apply(V, costs, dones, self.epsilon)
-        g_h = torch.autograd.grad(h_sum, params, retain_graph=True, allow_unused=True)
-        g_t = torch.autograd.grad(t_sum, params, allow_unused=True)
-        grads, hjb_loss, termination_loss = allreduce_and_mix(g_h, g_t, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]), params,
-                                                              regularization, self.epsilon, self.process_group if self._distributed() else False)
-        for p, gr in zip(params, grads):
+        params, model_params = leaves, params
+        if self._distributed():
+            g_h = torch.autograd.grad(h_sum, params, retain_graph=True, allow_unused=True)
+            g_t = torch.autograd.grad(t_sum, params, allow_unused=True)
+            grads, hjb_loss, termination_loss = allreduce_and_mix(g_h, g_t, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]), params,
+                                                                  regularization, self.epsilon, self.process_group)
+        else:
+            # one process: the normalisers are known before the backward pass, so ONE reverse sweep of the mixed loss gives
+            # grad(hjb) + regularization * grad(termination) (vhjb.py:282-284) in half the kernels
+            hjb_t = h_sum / (h_sums[1] + self.epsilon)
+            term_t = t_sum / (h_sums[2] + self.epsilon)
+            grads = torch.autograd.grad(hjb_t + regularization * term_t, params, allow_unused=True)
+            grads = [torch.zeros_like(p) if gr is None else gr for p, gr in zip(params, grads)]
+            hjb_loss, termination_loss = hjb_t.detach(), term_t.detach()
+        for p, gr in zip(model_params, grads):
             p.grad = gr
         self.optimizer.step()
         return hjb_loss + regularization * termination_loss, hjb_loss, termination_loss
+
+    def params_update_graphed(self, xs, dones, costs, regularization):
+        """`params_update` replayed from a hipGraph captured on first use for this minibatch shape: the same kernels in the
+        same order, without ~100 host-side launches per step.  The returned losses are views of the graph's static outputs:
+        consume them before the next call."""
+        xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
+        if self._reg_buf is None:
+            self._reg_buf = torch.zeros((), dtype=self.dtype, device=self.device)
+        self._reg_buf.fill_(float(regularization))
+        if self._graphed_update is None or not self._graphed_update.matches(xs, dones, costs, self._reg_buf):
+            self._graphed_update = GraphedStep(self.optimizer, list(self.value_function_approximator.parameters()), self._update_core,
+                                               (xs, dones, costs, self._reg_buf))
+        return self._graphed_update(xs, dones, costs, self._reg_buf)
 
     # -- training loop (vhjb.py:290-343) ---------------------------------------------------------------
     def train(self):
@@ -510,7 +551,8 @@ class VHJBController(Controller):
                 torch.distributed.all_reduce(nbt, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
                 nb = int(nbt.item())
             for xs, costs, dones in self.replay_buffer.batches(per_rank_batch, generator=self._gen, limit=nb):
-                total_loss, hjb_loss, termination_loss = self.params_update(xs, dones, costs, self.regularization)
+                update = self.params_update_graphed if self.graph_updates else self.params_update
+                total_loss, hjb_loss, termination_loss = update(xs, dones, costs, self.regularization)
                 total_losses = total_losses + total_loss
                 hjb_losses = hjb_losses + hjb_loss
                 termination_losses = termination_losses + termination_loss
@@ -535,6 +577,48 @@ class VHJBController(Controller):
 
         return (average_trajectory_cost_list, std_trajectory_cost_list, average_trajectory_length_list,
                 average_total_loss_list, average_hjb_loss_list, average_termination_loss_list)
+
+
+class GraphedStep:
+    """One optimiser step captured in a hipGraph (torch.cuda.CUDAGraph on ROCm).
+
+    `core(*inputs)` must run forward, backward and `optimizer.step()` with every tensor it reads being one of `inputs`, a
+    parameter or optimiser state.  The inputs become static buffers that are filled before each replay; parameters, Adam
+    moments and the step counter live at fixed addresses and are updated in place by the replayed kernels (Adam must be
+    built `capturable`).  The warm-up steps PyTorch requires before a capture run on a side stream and are undone afterwards
+    (parameters and optimiser state restored in place), so building the graph does not move the weights."""
+
+    def __init__(self, optimizer, params, core, example_inputs):
+        self.inputs = [t.detach().clone() for t in example_inputs]
+        self.shapes = [tuple(t.shape) for t in self.inputs]
+        dev = self.inputs[0].device
+        saved_p = [p.detach().clone() for p in params]
+        saved_s = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()} for p in params if p in optimizer.state}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # allocates Adam's state, rocBLAS workspaces and this library's reduce workspace
+                core(*self.inputs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():
+            for p, q in zip(params, saved_p):
+                p.copy_(q)
+                for k, v in optimizer.state[p].items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved_s[p][k]) if p in saved_s else v.zero_()
+                p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = core(*self.inputs)
+
+    def matches(self, *inputs) -> bool:
+        return [tuple(t.shape) for t in inputs] == self.shapes
+
+    def __call__(self, *inputs):
+        for buf, t in zip(self.inputs, inputs):
+            buf.copy_(t)
+        self.graph.replay()
+        return self.out
 
 
 # ------------------------------------------------------------------------------------------------

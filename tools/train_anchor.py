@@ -23,15 +23,16 @@ def main():
     ap.add_argument("--trajectories", type=int, default=20, help="rollouts per epoch (reference: 20)")
     ap.add_argument("--T", type=float, default=10.0)
     ap.add_argument("--starts", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=0, help="VHJBControllerConfig.seed (reference: 0)")
     args = ap.parse_args()
-    dyn, pol, mb = load_systems(args.env, epochs=args.epochs, num_of_trajectories_per_epoch=args.trajectories)
+    dyn, pol, mb = load_systems(args.env, epochs=args.epochs, num_of_trajectories_per_epoch=args.trajectories, seed=args.seed)
     t0 = time.time()
     lists = pol.train()
     train_s = time.time() - t0
     np.random.seed(123)
     res = test_policy(pol, dyn, mb, T=args.T, batch=args.starts)
     cl, cm = res["cost_learned"].sum(0), res["cost_model_based"].sum(0)
-    print(json.dumps(dict(env=args.env, epochs=args.epochs, updates=pol.update_counter, train_seconds=round(train_s, 1),
+    print(json.dumps(dict(env=args.env, seed=args.seed, epochs=args.epochs, updates=pol.update_counter, train_seconds=round(train_s, 1),
                           replay_records=len(pol.replay_buffer), avg_traj_len_first=lists[2][0], avg_traj_len_last=lists[2][-1],
                           hjb_loss_first=lists[4][0] if lists[4] else None, hjb_loss_last=lists[4][-1] if lists[4] else None,
                           mean_cost_learned=float(cl.mean()), mean_cost_model_based=float(cm.mean()),
