@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 101 /* major*100 + minor */
+#define HJBX_VERSION 102 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -241,10 +241,15 @@ int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, const float
  *   x (B,n): states at step t_first.            done_step (B,) int32 in/out (-1 = live), as hjbx_vhjb_step.
  *   traj (n_steps+1,B,n) or NULL: slab k = state at step t_first+k (slab 0 = x).     x_out (B,n) or NULL: final state.
  *   cost, done (n_steps,B): the tuples emitted at each step.   resid (n_steps,B) or NULL.   u_log (n_steps,B,m) or NULL.
- * A whole reference rollout is t_first = 0, n_steps = T_max + 1 (the last iteration emits the forced terminal tuple). */
+ * A whole reference rollout is t_first = 0, n_steps = T_max + 1 (the last iteration emits the forced terminal tuple).
+ *   env_order (B,) int32 or NULL: a permutation of 0..B-1 = the order in which environments are packed into the 32-wide
+ *   tiles of the kernel (all arrays stay indexed by environment).  A tile whose environments have all finished skips the
+ *   value network and only writes its log rows, so listing the live environments first (a stable sort by done_step >= 0,
+ *   refreshed between launches) makes a batch in which most environments have terminated cost what its live part
+ *   costs.  Results do not depend on the order. */
 int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                           int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
-                          float* resid, int32_t* done_step, float* x_out, int64_t B, void* stream);
+                          float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream);
 
 #ifdef __cplusplus
 }

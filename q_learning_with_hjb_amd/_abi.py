@@ -207,7 +207,7 @@ def lib() -> C.CDLL:
         L.hjbx_value_grad_f32.restype = C.c_int
         L.hjbx_value_grad_f32.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _VP]
         L.hjbx_vhjb_rollout_f32.restype = C.c_int
-        L.hjbx_vhjb_rollout_f32.argtypes = [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
+        L.hjbx_vhjb_rollout_f32.argtypes = [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")

@@ -219,20 +219,35 @@ def value_grad(sys, mlp_desc, x, want_v=True, want_grad=True):
 
 
 def vhjb_rollout(sys, task, mlp_desc, x, n_steps, T_max, done_step, t_first=0, integrator=_abi.EULER, log_traj=True, log_u=False,
-                 log_residual=False, want_x_out=False):
+                 log_residual=False, want_x_out=False, env_order=None, out=None):
     """`n_steps` closed-loop VHJB steps (value gradient + step) in ONE kernel launch (f32).  `done_step` (B,) int32 is
     updated in place.  Returns a dict of time-major device tensors: traj (n_steps+1,B,n) | None, cost, done
-    (n_steps,B), u (n_steps,B,m) | None, residual (n_steps,B) | None, x_out (B,n) | None."""
+    (n_steps,B), u (n_steps,B,m) | None, residual (n_steps,B) | None, x_out (B,n) | None.
+    `env_order` (B,) int32: permutation packing the environments into the kernel's tiles (live ones first = compaction).
+    `out`: dict of preallocated contiguous slabs to write into (keys traj / u / cost / done / residual, e.g. time slices of a
+    whole-horizon log) instead of fresh tensors."""
     B = x.shape[0]
     _chk(x, "x", (B, sys.n), torch.float32)
     _chk(done_step, "done_step", (B,), torch.int32)
     dev = x.device
-    traj = torch.empty((n_steps + 1, B, sys.n), dtype=torch.float32, device=dev) if log_traj else None
-    ulog = torch.empty((n_steps, B, sys.m), dtype=torch.float32, device=dev) if log_u else None
-    cost = torch.empty((n_steps, B), dtype=torch.float32, device=dev)
-    done = torch.empty((n_steps, B), dtype=torch.float32, device=dev)
-    resid = torch.empty((n_steps, B), dtype=torch.float32, device=dev) if log_residual else None
+    out = out or {}
+
+    def slab(key, shape, wanted):
+        t = out.get(key)
+        if t is not None:
+            _chk(t, key, shape, torch.float32)
+            return t
+        return torch.empty(shape, dtype=torch.float32, device=dev) if wanted else None
+
+    traj = slab("traj", (n_steps + 1, B, sys.n), log_traj)
+    ulog = slab("u", (n_steps, B, sys.m), log_u)
+    cost = slab("cost", (n_steps, B), True)
+    done = slab("done", (n_steps, B), True)
+    resid = slab("residual", (n_steps, B), log_residual)
     x_out = torch.empty_like(x) if want_x_out else None
+    if env_order is not None:
+        _chk(env_order, "env_order", (B,), torch.int32)
     check(lib().hjbx_vhjb_rollout_f32(sys.ptr, ref(task), ref(mlp_desc), int(integrator), int(t_first), int(n_steps), int(T_max), _p(x),
-                                      _p(traj), _p(ulog), _p(cost), _p(done), _p(resid), _p(done_step), _p(x_out), B, _stream()))
+                                      _p(traj), _p(ulog), _p(cost), _p(done), _p(resid), _p(done_step), _p(x_out), _p(env_order), B,
+                                      _stream()))
     return dict(traj=traj, u=ulog, cost=cost, done=done, residual=resid, x_out=x_out)

@@ -282,6 +282,8 @@ class VHJBController(Controller):
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen)
         self.fused_value_grad = (dtype == torch.float32) if fused_value_grad is None else bool(fused_value_grad)
+        # fused rollouts of big batches re-pack live environments every `compaction_interval` steps (0 = never)
+        self.compaction_interval, self.compaction_min_batch = 16, 8192
         self.train_mode = False
         # the optimiser step of `train` is replayed from a hipGraph (about 100 launch-bound kernels at batch 256); the
         # data-parallel path keeps eager launches around its all-reduce
@@ -384,12 +386,39 @@ class VHJBController(Controller):
         B, n = x0.shape
         sysh, task, integ = self.dynamics.system, self._task, self.dynamics.integrator
         if self.fused_value_grad and self.dtype == torch.float32:
-            # the whole loop (T live steps + the forced terminal iteration) in one persistent kernel launch
             done_step = torch.full((B,), -1, dtype=torch.int32, device=self.device)
-            out = _ops.vhjb_rollout(sysh, task, self.value_function_approximator.descriptor(), x0, T + 1, T, done_step, integrator=integ,
-                                    log_traj=True, log_u=log_u, log_residual=log_residual)
-            return dict(traj=out["traj"][:T + 1], cost=out["cost"], done=out["done"], done_step=done_step,
-                        u=None if out["u"] is None else out["u"][:T], residual=out["residual"])
+            desc = self.value_function_approximator.descriptor()
+            chunk = self.compaction_interval if (self.compaction_interval and B >= self.compaction_min_batch) else 0
+            if not chunk or chunk >= T + 1:
+                # the whole loop (T live steps + the forced terminal iteration) in one persistent kernel launch
+                out = _ops.vhjb_rollout(sysh, task, desc, x0, T + 1, T, done_step, integrator=integ,
+                                        log_traj=True, log_u=log_u, log_residual=log_residual)
+                return dict(traj=out["traj"][:T + 1], cost=out["cost"], done=out["done"], done_step=done_step,
+                            u=None if out["u"] is None else out["u"][:T], residual=out["residual"])
+            # large batches: launches of `chunk` steps; between them the environments are re-packed into the kernel's tiles
+            # with the live ones first (device-side argsort, no host sync), so tiles of finished environments skip the network
+            S = T + 1
+            traj = torch.empty((S + 1, B, n), dtype=self.dtype, device=self.device)
+            cost = torch.empty((S, B), dtype=self.dtype, device=self.device)
+            done = torch.empty_like(cost)
+            ulog = torch.empty((S, B, self.control_dim), dtype=self.dtype, device=self.device) if log_u else None
+            resid = torch.empty_like(cost) if log_residual else None
+            t0, order = 0, None
+            x_cur = x0
+            while t0 < S:
+                k = min(chunk, S - t0)
+                slabs = dict(traj=traj[t0:t0 + k + 1], cost=cost[t0:t0 + k], done=done[t0:t0 + k])
+                if log_u:
+                    slabs["u"] = ulog[t0:t0 + k]
+                if log_residual:
+                    slabs["residual"] = resid[t0:t0 + k]
+                _ops.vhjb_rollout(sysh, task, desc, x_cur, k, T, done_step, t_first=t0, integrator=integ, log_traj=True, log_u=log_u,
+                                  log_residual=log_residual, env_order=order, out=slabs)
+                t0 += k
+                x_cur = traj[t0]
+                if t0 < S:
+                    order = torch.argsort((done_step >= 0).to(torch.int8), stable=True).to(torch.int32)
+            return dict(traj=traj[:T + 1], cost=cost, done=done, done_step=done_step, u=None if ulog is None else ulog[:T], residual=resid)
         traj = torch.empty((T + 2, B, n), dtype=self.dtype, device=self.device)  # slot T+1 is scratch for the last call
         cost = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)
         done = torch.empty((T + 1, B), dtype=self.dtype, device=self.device)

@@ -451,28 +451,48 @@ template <int N, int M> struct RolloutOut {
 };
 
 template <int INTEG, typename S, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys, MlpP<S::N> p, TaskP<float, S::N, S::M> tk,
-                                                                           Limits<float, S::M> lim, const float* __restrict__ W1g,
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
+                                                                           Limits<float, S::M> lim_k, const float* __restrict__ W1g,
                                                                            const float* __restrict__ W2g, const float* __restrict__ W3g,
                                                                            int t_first, int n_steps, int T_max, const float* __restrict__ x,
-                                                                           RolloutOut<S::N, S::M> o, int64_t B, int64_t ngroups) {
+                                                                           const int32_t* __restrict__ order, RolloutOut<S::N, S::M> o, int64_t B,
+                                                                           int64_t ngroups) {
     constexpr int N = S::N, M = S::M;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
     __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    // System, task, limits and normalisation constants are staged in LDS: as kernel arguments they are ~100-250 wave-uniform
+    // scalars that do not fit the SGPR file next to the address arithmetic, and hipcc spilled them to VGPR lanes
+    // (hundreds of v_readlane / v_writelane per step, some inside the MFMA chains).  LDS broadcast reads cost no SGPRs.
+    __shared__ S sys_s;
+    __shared__ MlpP<N> p_s;
+    __shared__ TaskP<float, N, M> tk_s;
+    __shared__ Limits<float, M> lim_s;
     const int tid = threadIdx.x;
-    if (tid == 0) L.next = WAVES;
+    if (tid == 0) {
+        L.next = WAVES;
+        sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k;
+    }
     mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     __syncthreads();
+    const S& sys = sys_s;
+    const MlpP<N>& p = p_s;
+    const TaskP<float, N, M>& tk = tk_s;
+    const Limits<float, M>& lim = lim_s;
     const int lane = tid & 63, wave = tid >> 6;
     const MlpCtx c = mlp_ctx<N>(L, lane);
     const int i = c.i, h = c.h;
+    // Natural order: each workgroup owns a contiguous range of tile groups and its waves pull from it through the LDS counter
+    // (measured 12 % faster at B = 2^18 than dealing single groups round-robin).  With `order` the live environments come first,
+    // so the groups are dealt round-robin (group = blockIdx + k gridDim) to spread the live tiles over all CUs.
     const int64_t groups_per_wg = (ngroups + gridDim.x - 1) / gridDim.x;
     const int64_t g_begin = (int64_t)blockIdx.x * groups_per_wg;
-    const int64_t g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
-
-    for (int64_t grp = g_begin + wave; grp < g_end;) {
-        const int64_t env = grp * 32 + i;
-        const bool valid = env < B;
+    for (int64_t pick = wave;;) {
+        const int64_t grp = order ? (int64_t)blockIdx.x + pick * (int64_t)gridDim.x : g_begin + pick;
+        if (grp >= ngroups || (!order && pick >= groups_per_wg)) break;
+        const int64_t slot = grp * 32 + i;
+        const bool valid = slot < B;
+        int64_t env = valid ? (order ? (int64_t)order[slot] : slot) : 0;
+        env = env < 0 ? 0 : (env >= B ? B - 1 : env);  // a corrupt `order` entry must not become an out-of-bounds access
         const bool writer = valid && h == 0;  // both lane halves carry the same environment; half 0 stores
         float xs[1][N];
         int32_t ds = 0;                        // padding lanes are "done": they hold xf and emit nothing
@@ -486,10 +506,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
         if (o.traj && writer) store_row<N>(o.traj, env, xs[0]);
         for (int k = 0; k < n_steps; ++k) {
             asm volatile("" ::: "memory");
-            float V[1], g[1][N];
-            mlp_value_grad<S, 1>(sys, p, c, xs, true, V, g);
             float xo[N], u[M], cst, dn, res;
-            vhjb_step_env<INTEG>(sys, tk, lim, t_first + k, T_max, o.resid != nullptr, xs[0], g[0], ds, xo, u, cst, dn, res);
+            if (__builtin_amdgcn_ballot_w64(ds < 0) == 0) {
+                // every environment of this tile has finished: vhjb_step_env would emit zeros and hold the state whatever the
+                // value gradient is, so the network is skipped (a finished tile costs its log writes only).  Kept as a separate
+                // arm: sharing vhjb_step_env behind a conditional network call made hipcc spill the prefetched weights.
+#pragma unroll
+                for (int q = 0; q < N; ++q) xo[q] = xs[0][q];
+#pragma unroll
+                for (int j = 0; j < M; ++j) u[j] = 0.0f;
+                cst = dn = res = 0.0f;
+            } else {
+                float V[1], g[1][N];
+                mlp_value_grad<S, 1>(sys, p, c, xs, true, V, g);
+                vhjb_step_env<INTEG>(sys, tk, lim, t_first + k, T_max, o.resid != nullptr, xs[0], g[0], ds, xo, u, cst, dn, res);
+            }
             if (writer) {
                 const int64_t row = (int64_t)k * B + env;
                 o.cost[row] = cst;
@@ -507,7 +538,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
         }
         int nxt = 0;
         if (lane == 0) nxt = atomicAdd(&L.next, 1);
-        grp = g_begin + __builtin_amdgcn_readfirstlane(nxt);
+        pick = __builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
@@ -571,7 +602,7 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
 template <typename S>
 static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                                int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done, float* resid,
-                               int32_t* done_step, float* x_out, int64_t B, void* st) {
+                               int32_t* done_step, float* x_out, const int32_t* order, int64_t B, void* st) {
     constexpr int N = S::N, M = S::M;
     constexpr int WAVES = HJBX_MLP_WAVES;
     MlpP<N> p;
@@ -593,13 +624,13 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
     if (integrator == HJBX_EULER)
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
-                           W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
+                           W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
     else if (integrator == HJBX_RK4)
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<1, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
-                           W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
+                           W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
     else if constexpr (S::kHasZoh)
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<2, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
-                           W2, W3, t_first, n_steps, T_max, x, o, B, ngroups);
+                           W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_vhjb_rollout_f32: %s", hipGetErrorString(e));
     return HJBX_OK;
@@ -607,7 +638,7 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
 
 extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                                      int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
-                                     float* resid, int32_t* done_step, float* x_out, int64_t B, void* stream) {
+                                     float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream) {
     if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: NULL system, task or mlp descriptor");
     if (int rc = check_task(task)) return rc;
     if (B < 0 || n_steps < 0 || t_first < 0 || T_max < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: negative size or step index");
@@ -632,7 +663,7 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
         using SS = decltype(S);
         if constexpr (SS::N % 2 == 0)
             rc = launch_vhjb_rollout<SS>(sys, S, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step,
-                                         x_out, B, stream);
+                                         x_out, env_order, B, stream);
     });
     if (!ok || rc == HJBX_EUNSUPPORTED)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);

@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     L = _abi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), f"libhjbx.so does not export {name}"
-    assert L.hjbx_version() == 101
+    assert L.hjbx_version() == 102
     assert L.hjbx_reduce_workspace_bytes() >= 3 * 8
 
 
