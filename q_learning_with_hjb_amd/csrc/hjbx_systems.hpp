@@ -323,19 +323,17 @@ HJBX_DEV void control_from_grad(const TaskP<T, S::N, S::M>& tk, const Limits<T, 
         for (int i = 0; i < N; ++i) acc += f2[i * M + j] * g[i];
         f2tg[j] = acc;
     }
-    if (tk.law != 0) {
-#pragma unroll
-        for (int j = 0; j < M; ++j) u_raw[j] = u[j] = (f2tg[j] < T(0)) ? lim.umax[j] : ((f2tg[j] > T(0)) ? lim.umin[j] : T(0));
-        return;
-    }
+    const bool bang = tk.law != 0;  // selected per element, not by an early return: keeps u / u_raw in registers (no scratch)
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         T acc = T(0);
 #pragma unroll
         for (int k = 0; k < M; ++k) acc += tk.Rinv[j * M + k] * f2tg[k];
-        u_raw[j] = -acc / T(2) + tk.uf[j];
+        const T quad = -acc / T(2) + tk.uf[j];
+        const T bb = (f2tg[j] < T(0)) ? lim.umax[j] : ((f2tg[j] > T(0)) ? lim.umin[j] : T(0));
+        u_raw[j] = bang ? bb : quad;
+        u[j] = bang ? bb : clamp_t(quad, lim.umin[j], lim.umax[j]);
     }
-    clip_u<T, M>(lim, u_raw, u);
 }
 
 // running cost given the error coordinates: e'Qe + (u-uf)'R(u-uf)   (vhjb.py:162-165); HJBX_LAW_BANGBANG: 1 outside the
