@@ -23,12 +23,14 @@ template <int CH, int VN, int MODE> __global__ __launch_bounds__(512) void k(flo
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if (MODE == 3) __builtin_amdgcn_s_setprio(0);
+        if (MODE == 4) __builtin_amdgcn_s_setprio(3);  // chains run at raised priority: a ready MFMA wins the issue port
 #pragma unroll
         for (int u = 0; u < CH / 4; ++u) {
             acc[0] = MFMA(a0, b, acc[0]); acc[1] = MFMA(a0, b, acc[1]); acc[2] = MFMA(a0, b, acc[2]); acc[3] = MFMA(a0, b, acc[3]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE == 3) __builtin_amdgcn_s_setprio(2);  // VALU phases run at raised priority
+        if (MODE == 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int v = 0; v < VN; ++v) {
             acc[(v >> 4) & 3][v & 15] = __builtin_fmaxf(acc[(v >> 4) & 3][v & 15] * 0.999f, -1.0f);  // 2 VALU ops per element
@@ -84,5 +86,8 @@ int main() {
     run<256, 64, 3>(512, "VALU phases at s_setprio 2");
     run<256, 256, 3>(512, "VALU phases at s_setprio 2");
     run<128, 256, 3>(512, "VALU phases at s_setprio 2");
+    run<256, 64, 4>(512, "MFMA chains at s_setprio 3");
+    run<256, 256, 4>(512, "MFMA chains at s_setprio 3");
+    run<128, 256, 4>(512, "MFMA chains at s_setprio 3");
     return 0;
 }
