@@ -25,7 +25,9 @@ def test_abi_exports_every_declared_symbol():
     L = _abi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), f"libhjbx.so does not export {name}"
-    assert L.hjbx_version() == 102
+    import re
+    want = int(re.search(r"#define HJBX_VERSION (\d+)", open(os.path.join(ROOT, "include", "hjbx.h")).read()).group(1))
+    assert L.hjbx_version() == want >= 100
     assert L.hjbx_reduce_workspace_bytes() >= 3 * 8
 
 
@@ -258,3 +260,9 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     assert audit_asm_loads.audit(str(asm)) == 0
     text = asm.read_text()
     assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
+
+
+def test_graft_entry_build_check_passes():
+    """The driver's "does it build" hook: compiles (no-op when current), loads the library, checks symbols and version."""
+    import __graft_entry__ as g
+    g.build()
