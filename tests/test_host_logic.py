@@ -25,7 +25,6 @@ def test_abi_exports_every_declared_symbol():
     L = _abi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), f"libhjbx.so does not export {name}"
-    import re
     want = int(re.search(r"#define HJBX_VERSION (\d+)", open(os.path.join(ROOT, "include", "hjbx.h")).read()).group(1))
     assert L.hjbx_version() == want >= 100
     assert L.hjbx_reduce_workspace_bytes() >= 3 * 8
