@@ -246,7 +246,7 @@ class VHJBController(Controller):
 
     def __init__(self, dynamics: Dynamics, config, device=None, dtype=torch.float32, process_group=None,
                  residual_mode=_abi.RESIDUAL_NORMALISED, fused_value_grad: Optional[bool] = None,
-                 graph_updates: Optional[bool] = None) -> None:
+                 graph_updates: Optional[bool] = None, activation: str = "relu") -> None:
         super().__init__()
         self.device = torch.device(device) if device is not None else _ops.require_device()
         self.dtype = dtype
@@ -280,8 +280,11 @@ class VHJBController(Controller):
 
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
-            config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen)
-        self.fused_value_grad = (dtype == torch.float32) if fused_value_grad is None else bool(fused_value_grad)
+            config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen, activation=activation)
+        # activation: "relu" = controller/vhjb.py; "tanh" / "sin" = the notebooks' networks (PyTorch path only)
+        self.fused_value_grad = (dtype == torch.float32 and activation == "relu") if fused_value_grad is None else bool(fused_value_grad)
+        if self.fused_value_grad and activation != "relu":
+            raise NotImplementedError("the fused value-gradient kernel implements the ReLU network only")
         # fused rollouts of big batches re-pack live environments every `compaction_interval` steps (0 = never)
         self.compaction_interval, self.compaction_min_batch = 16, 8192
         self.train_mode = False

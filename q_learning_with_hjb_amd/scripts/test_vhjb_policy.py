@@ -41,7 +41,7 @@ _ENVS = {
 }
 
 
-def load_systems(env_name, dynamics_config=None, vhjb_controller_config=None, **controller_overrides):
+def load_systems(env_name, dynamics_config=None, vhjb_controller_config=None, activation="relu", **controller_overrides):
     """-> (dynamics, nn_policy, model_based_policy); config files are gin files of the reference's format."""
     cfg_cls, stock_dyn, dyn_cls, stock_ctl = _ENVS[env_name]
     if dynamics_config is None:
@@ -55,7 +55,7 @@ def load_systems(env_name, dynamics_config=None, vhjb_controller_config=None, **
         gin_lite.parse_config_file(vhjb_controller_config)
         ccfg = VHJBControllerConfig(**controller_overrides)
     dynamics = dyn_cls(dcfg)
-    nn_policy = VHJBController(dynamics, ccfg)
+    nn_policy = VHJBController(dynamics, ccfg, activation=activation)
     Q, R = np.asarray(ccfg.Q, np.float64), np.asarray(ccfg.R, np.float64)
     if env_name == "lqr":
         model_based = LQR(dynamics, Q, R)

@@ -24,15 +24,28 @@ def main():
     ap.add_argument("--T", type=float, default=10.0)
     ap.add_argument("--starts", type=int, default=10)
     ap.add_argument("--seed", type=int, default=0, help="VHJBControllerConfig.seed (reference: 0)")
+    ap.add_argument("--activation", default="relu", choices=["relu", "tanh", "sin"], help="relu = controller/vhjb.py; tanh = the notebooks")
+    ap.add_argument("--notebook", action="store_true", help="the notebooks' recipe (examples/cartpole_balancing.ipynb cell 10, "
+                    "drone_hovering.ipynb cell 10): data set seeded with 256 copies of xf, no boundary set, no termination loss")
     args = ap.parse_args()
-    dyn, pol, mb = load_systems(args.env, epochs=args.epochs, num_of_trajectories_per_epoch=args.trajectories, seed=args.seed)
+    over = {}
+    if args.notebook:
+        over = dict(num_of_interior_data=256, num_of_boundary_data=0, regularization_peak_value=0.0, regularization_init_value=0.0,
+                    regularization_end_value=0.0)
+        if args.env == "quadrotors2DHovering":      # examples/drone_hovering.ipynb cell 4 uses a wider position box than the gin file
+            over.update(obs_min=[-3, -3, -1.5, -5, -5, -2], obs_max=[3, 3, 1.5, 5, 5, 2])
+    dyn, pol, mb = load_systems(args.env, epochs=args.epochs, num_of_trajectories_per_epoch=args.trajectories, seed=args.seed,
+                                activation=args.activation, **over)
+    if args.notebook:      # 256 copies of xf, not a box around it
+        rb = pol.replay_buffer
+        rb.x[:rb.size] = torch.as_tensor(np.asarray(pol.xf, np.float64), dtype=rb.x.dtype, device=rb.x.device)
     t0 = time.time()
     lists = pol.train()
     train_s = time.time() - t0
     np.random.seed(123)
     res = test_policy(pol, dyn, mb, T=args.T, batch=args.starts)
     cl, cm = res["cost_learned"].sum(0), res["cost_model_based"].sum(0)
-    print(json.dumps(dict(env=args.env, seed=args.seed, epochs=args.epochs, updates=pol.update_counter, train_seconds=round(train_s, 1),
+    print(json.dumps(dict(env=args.env, seed=args.seed, activation=args.activation, notebook=args.notebook, epochs=args.epochs, updates=pol.update_counter, train_seconds=round(train_s, 1),
                           replay_records=len(pol.replay_buffer), avg_traj_len_first=lists[2][0], avg_traj_len_last=lists[2][-1],
                           hjb_loss_first=lists[4][0] if lists[4] else None, hjb_loss_last=lists[4][-1] if lists[4] else None,
                           mean_cost_learned=float(cl.mean()), mean_cost_model_based=float(cm.mean()),
