@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 102 /* major*100 + minor */
+#define HJBX_VERSION 103 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -125,6 +125,12 @@ typedef struct hjbx_controller {
     double eps_region;  /* ACROBOT_ENERGY: LQR region; DI_TIME_OPTIMAL / STOP_AT_TARGET: squared radius of the target ball */
 } hjbx_controller;
 
+typedef enum hjbx_activation {
+    HJBX_ACT_RELU = 0, /* controller/vhjb.py:52,56 and examples/drone_hovering.ipynb, 10D_quadcopte.ipynb */
+    HJBX_ACT_TANH = 1, /* examples/cartpole_balancing.ipynb cell 6 */
+    HJBX_ACT_SIN = 2   /* examples/double_integrator_optimal_time.ipynb cell 5 (no fused kernel: HJBX_EUNSUPPORTED) */
+} hjbx_activation;
+
 /* Value network of controller/vhjb.py:17-60 (no bias, BatchNorm off): device weight pointers,
  * Flax Dense layout (in, out) row-major, y = x @ W. */
 typedef struct hjbx_mlp {
@@ -132,7 +138,7 @@ typedef struct hjbx_mlp {
     const void* W2; /* (h1, h2) */
     const void* W3; /* (h2, h3) */
     int32_t h1, h2, h3;
-    int32_t _pad;
+    int32_t activation;      /* hjbx_activation between the Dense layers */
     double mean[HJBX_MAX_N]; /* normalization_mean */
     double std[HJBX_MAX_N];  /* normalization_std  */
     double xf[HJBX_MAX_N];

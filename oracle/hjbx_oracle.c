@@ -31,7 +31,7 @@ typedef struct orc_system {
 
 /* value-network hyper-parameters (weights are passed as separate host arrays) */
 typedef struct orc_mlp {
-    int32_t h1, h2, h3, _pad;
+    int32_t h1, h2, h3, activation; /* hjbx_activation */
     double mean[HJBX_MAX_N], std[HJBX_MAX_N], xf[HJBX_MAX_N];
     double eps_scalar;
 } orc_mlp;

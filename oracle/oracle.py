@@ -25,7 +25,7 @@ class OrcSystem(C.Structure):
 
 
 class OrcMlp(C.Structure):
-    _fields_ = [("h1", C.c_int32), ("h2", C.c_int32), ("h3", C.c_int32), ("_pad", C.c_int32), ("mean", C.c_double * MAXN),
+    _fields_ = [("h1", C.c_int32), ("h2", C.c_int32), ("h3", C.c_int32), ("activation", C.c_int32), ("mean", C.c_double * MAXN),
                 ("std", C.c_double * MAXN), ("xf", C.c_double * MAXN), ("eps_scalar", C.c_double)]
 
 
@@ -90,8 +90,9 @@ class System:
         return cls(h.kind, h.n, h.m, h.dt, h.umin, h.umax, h.params)
 
 
-def make_mlp(features, mean, std, xf, eps_scalar):
+def make_mlp(features, mean, std, xf, eps_scalar, activation=0):
     p = OrcMlp()
+    p.activation = {"relu": 0, "tanh": 1, "sin": 2}.get(activation, activation)
     p.h1, p.h2, p.h3 = (int(f) for f in features)
     _abi._fill(p.mean, mean)
     _abi._fill(p.std, std)

@@ -311,7 +311,7 @@ static REAL FN(hjb_residual1)(const orc_system* s, const hjbx_task* t, int mode,
  * (get_v_gradient, vhjb.py:201-202) by hand-written reverse mode. PARITY UNPINNED.
  * W1 (n,h1), W2 (h1,h2), W3 (h2,h3) row-major = Flax Dense kernels, y = x @ W. */
 static REAL FN(value_grad1)(const orc_system* s, const orc_mlp* p, const REAL* W1, const REAL* W2, const REAL* W3,
-                            const REAL* x, REAL* g /* n or NULL */, REAL* scratch /* 2*(h1+h2)+h3 */) {
+                            const REAL* x, REAL* g /* n or NULL */, REAL* scratch /* 3*(h1+h2)+h3 */) {
     const int n = s->n, h1 = p->h1, h2 = p->h2, h3 = p->h3;
     REAL e[HJBX_MAX_N], z[HJBX_MAX_N];
     REAL *a1 = scratch, *a2 = a1 + h1, *y = a2 + h2, *d1 = y + h3, *d2 = d1 + h1;
@@ -320,10 +320,21 @@ static REAL FN(value_grad1)(const orc_system* s, const orc_mlp* p, const REAL* W
     for (int i = 0; i < n; ++i) { ee += e[i] * e[i]; z[i] = (e[i] - (REAL)p->mean[i]) / (REAL)p->std[i]; }
     for (int j = 0; j < h1; ++j) a1[j] = 0;
     for (int i = 0; i < n; ++i) for (int j = 0; j < h1; ++j) a1[j] += z[i] * W1[i * h1 + j];
-    for (int j = 0; j < h1; ++j) a1[j] = a1[j] > 0 ? a1[j] : 0;
+    /* activation: relu (vhjb.py:52,56) or the notebooks' tanh / sin; a1, a2 hold the activations, s1, s2 their derivatives */
+    const int act = p->activation;
+    REAL *s1 = d2 + h2, *s2 = s1 + h1;
+#define ORC_ACT(v, dv)                                                                                             \
+    do {                                                                                                           \
+        const REAL zz = (v);                                                                                       \
+        if (act == HJBX_ACT_TANH) { const REAL t = (REAL)tanh((double)zz); (v) = t; (dv) = 1 - t * t; }           \
+        else if (act == HJBX_ACT_SIN) { (v) = (REAL)sin((double)zz); (dv) = (REAL)cos((double)zz); }               \
+        else { (v) = zz > 0 ? zz : 0; (dv) = zz > 0 ? (REAL)1 : (REAL)0; }                                         \
+    } while (0)
+    for (int j = 0; j < h1; ++j) ORC_ACT(a1[j], s1[j]);
     for (int j = 0; j < h2; ++j) a2[j] = 0;
     for (int i = 0; i < h1; ++i) { const REAL a = a1[i]; if (a != 0) for (int j = 0; j < h2; ++j) a2[j] += a * W2[i * h2 + j]; }
-    for (int j = 0; j < h2; ++j) a2[j] = a2[j] > 0 ? a2[j] : 0;
+    for (int j = 0; j < h2; ++j) ORC_ACT(a2[j], s2[j]);
+#undef ORC_ACT
     for (int j = 0; j < h3; ++j) y[j] = 0;
     for (int i = 0; i < h2; ++i) { const REAL a = a2[i]; if (a != 0) for (int j = 0; j < h3; ++j) y[j] += a * W3[i * h3 + j]; }
     REAL V = 0;
@@ -332,13 +343,13 @@ static REAL FN(value_grad1)(const orc_system* s, const orc_mlp* p, const REAL* W
     if (g) {
         for (int i = 0; i < h2; ++i) {
             REAL acc = 0;
-            if (a2[i] > 0) for (int j = 0; j < h3; ++j) acc += W3[i * h3 + j] * (2 * y[j]);
-            d2[i] = acc;
+            if (s2[i] != 0) for (int j = 0; j < h3; ++j) acc += W3[i * h3 + j] * (2 * y[j]);
+            d2[i] = acc * s2[i];
         }
         for (int i = 0; i < h1; ++i) {
             REAL acc = 0;
-            if (a1[i] > 0) for (int j = 0; j < h2; ++j) acc += W2[i * h2 + j] * d2[j];
-            d1[i] = acc;
+            if (s1[i] != 0) for (int j = 0; j < h2; ++j) acc += W2[i * h2 + j] * d2[j];
+            d1[i] = acc * s1[i];
         }
         for (int i = 0; i < n; ++i) {
             REAL acc = 0;
@@ -507,7 +518,7 @@ void FN(orc_value_grad)(const orc_system* s, const orc_mlp* p, const REAL* W1, c
                         const REAL* x, REAL* V, REAL* g, int64_t B) {
 #pragma omp parallel
     {
-        REAL* scratch = (REAL*)malloc(sizeof(REAL) * (size_t)(2 * (p->h1 + p->h2) + p->h3));
+        REAL* scratch = (REAL*)malloc(sizeof(REAL) * (size_t)(3 * (p->h1 + p->h2) + p->h3));
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             const REAL v = FN(value_grad1)(s, p, W1, W2, W3, x + b * s->n, g ? g + b * s->n : NULL, scratch);
@@ -568,7 +579,7 @@ int64_t FN(orc_vhjb_rollout)(const orc_system* s, const hjbx_task* t, const orc_
     int64_t live_steps = 0;
 #pragma omp parallel reduction(+ : live_steps)
     {
-        REAL* scratch = (REAL*)malloc(sizeof(REAL) * (size_t)(2 * (p->h1 + p->h2) + p->h3));
+        REAL* scratch = (REAL*)malloc(sizeof(REAL) * (size_t)(3 * (p->h1 + p->h2) + p->h3));
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             REAL x[HJBX_MAX_N], g[HJBX_MAX_N], xn[HJBX_MAX_N], u[HJBX_MAX_M], ur[HJBX_MAX_M];

@@ -21,6 +21,7 @@ EULER, RK4, ZOH = 0, 1, 2
 RESIDUAL_NORMALISED, RESIDUAL_RAW = 0, 1
 CTRL_LINEAR_FEEDBACK, CTRL_CARTPOLE_ENERGY, CTRL_ACROBOT_ENERGY, CTRL_DI_TIME_OPTIMAL = 0, 1, 2, 3
 LAW_QUADRATIC, LAW_BANGBANG = 0, 1
+ACT_RELU, ACT_TANH, ACT_SIN = 0, 1, 2
 ROLLOUT_TERMINATE = 1
 ROLLOUT_STOP_AT_TARGET = 2
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
@@ -74,7 +75,7 @@ class HjbxMlp(C.Structure):
         ("h1", C.c_int32),
         ("h2", C.c_int32),
         ("h3", C.c_int32),
-        ("_pad", C.c_int32),
+        ("activation", C.c_int32),
         ("mean", C.c_double * HJBX_MAX_N),
         ("std", C.c_double * HJBX_MAX_N),
         ("xf", C.c_double * HJBX_MAX_N),

@@ -71,7 +71,7 @@ class TimeOptimalVHJBController(Controller):
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, features, np.zeros(n), np.ones(n), self.xf, epsilon_scalar, dtype=self.dtype, device=self.device,
             generator=self._gen, activation=activation)
-        self.fused = activation == "relu" and self.dtype == torch.float32 and tuple(features) == (128, 128, 64)
+        self.fused = activation in ("relu", "tanh") and self.dtype == torch.float32 and tuple(features) == (128, 128, 64)
         self.graph_updates = self.device.type == "cuda"   # optimiser steps of `train` replay from a hipGraph
         self._graphed = None
         self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8,

@@ -44,8 +44,9 @@ class ValueFunctionApproximator(torch.nn.Module):
     with ReLU between them so that V(xf) = 0 (reference vhjb.py:17-60).  Kernels are stored
     (in, out) and applied as `x @ W`, like Flax.  `activation` "sin" / "tanh" give the notebook variants
     (examples/double_integrator_optimal_time.ipynb cell 5, examples/cartpole_balancing.ipynb): odd functions
-    with act(0) = 0, so V(xf) = 0 still holds; the fused MFMA kernel exists for "relu" only."""
+    with act(0) = 0, so V(xf) = 0 still holds; the fused MFMA kernels exist for "relu" and "tanh"."""
 
+    FUSED_ACTIVATIONS = ("relu", "tanh")   # hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 exist for these
     _ACT = {"relu": (torch.relu, lambda a: (a > 0).to(a.dtype)),
             "sin": (torch.sin, torch.cos),
             "tanh": (torch.tanh, lambda a: 1.0 - torch.tanh(a) ** 2)}
@@ -133,6 +134,7 @@ class ValueFunctionApproximator(torch.nn.Module):
         W1, W2, W3 = self.weights
         d.W1, d.W2, d.W3 = W1.data_ptr(), W2.data_ptr(), W3.data_ptr()
         d.h1, d.h2, d.h3 = self.features
+        d.activation = {"relu": _abi.ACT_RELU, "tanh": _abi.ACT_TANH, "sin": _abi.ACT_SIN}[self.activation]
         _abi._fill(d.mean, self._np["mean"])
         _abi._fill(d.std, self._np["std"])
         _abi._fill(d.xf, self._np["xf"])
@@ -142,8 +144,8 @@ class ValueFunctionApproximator(torch.nn.Module):
     @torch.no_grad()
     def fused_value_grad(self, x: torch.Tensor, want_v=True, want_grad=True):
         """Inference-only V and dV/dx from the fused MFMA kernel (float32)."""
-        if self.activation != "relu":
-            raise NotImplementedError("the fused value-gradient kernel implements the reference's ReLU network only")
+        if self.activation not in self.FUSED_ACTIVATIONS:
+            raise NotImplementedError(f"no fused value-gradient kernel for the {self.activation} activation (relu and tanh only)")
         for w in self.weights:
             assert w.is_contiguous() and w.dtype == torch.float32
         return _ops.value_grad(self.dynamics.system, self.descriptor(), x, want_v, want_grad)
@@ -281,10 +283,11 @@ class VHJBController(Controller):
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen, activation=activation)
-        # activation: "relu" = controller/vhjb.py; "tanh" / "sin" = the notebooks' networks (PyTorch path only)
-        self.fused_value_grad = (dtype == torch.float32 and activation == "relu") if fused_value_grad is None else bool(fused_value_grad)
-        if self.fused_value_grad and activation != "relu":
-            raise NotImplementedError("the fused value-gradient kernel implements the ReLU network only")
+        # activation: "relu" = controller/vhjb.py; "tanh" / "sin" = the notebooks' networks ("sin": PyTorch path only)
+        fusable = activation in ValueFunctionApproximator.FUSED_ACTIVATIONS
+        self.fused_value_grad = (dtype == torch.float32 and fusable) if fused_value_grad is None else bool(fused_value_grad)
+        if self.fused_value_grad and not fusable:
+            raise NotImplementedError(f"no fused value-gradient kernel for the {activation} activation")
         # fused rollouts of big batches re-pack live environments every `compaction_interval` steps (0 = never)
         self.compaction_interval, self.compaction_min_batch = 16, 8192
         self.train_mode = False

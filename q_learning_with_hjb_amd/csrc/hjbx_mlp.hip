@@ -24,6 +24,7 @@
 //    finish together.
 // Per environment: 4(128 n + 128*128 + 128*64) flop; algorithmic HBM traffic 4(2n+1) bytes -> MFMA bound.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstddef>
 
@@ -62,6 +63,24 @@ __device__ __forceinline__ constexpr int perm(int s) { return (s & 3) + 8 * (s >
 __device__ __forceinline__ float relu1(float v) {
     const int b = __builtin_bit_cast(int, v);
     return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// tanh for the notebooks' networks (hjbx_mlp.activation = HJBX_ACT_TANH): 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp
+// units (5 VALU ops, two of them quarter rate); absolute error ~1e-7 over the whole range (exp2 overflow -> +1, underflow -> -1),
+// which is what matters for V = |y|^2 and its gradient.  The derivative comes from the value: 1 - tanh^2.
+__device__ __forceinline__ float tanh1(float v) {
+    const float ex = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);  // exp(2x) = 2^(2x log2 e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(ex + 1.0f);
+}
+// ACT = hjbx_activation: the activation applied in place to a pre-activation, and the back-propagation factor d * act'(z)
+// written in terms of the ACTIVATION h = act(z) (relu: [h > 0]; tanh: 1 - h^2), so no pre-activation has to be kept
+template <int ACT> __device__ __forceinline__ float act1(float v) {
+    if constexpr (ACT == HJBX_ACT_TANH) return tanh1(v);
+    else return relu1(v);
+}
+template <int ACT> __device__ __forceinline__ float dact1(float h, float d) {
+    if constexpr (ACT == HJBX_ACT_TANH) return d - d * h * h;
+    else return h > 0.f ? d : 0.f;
 }
 
 // ---- software-pipelined MFMA chain ------------------------------------------------------------------------
@@ -198,7 +217,7 @@ template <int N> __device__ __forceinline__ MlpCtx mlp_ctx(MlpLds<N>& L, int lan
 
 // V and dV/dx of the TL tiles whose state rows are in xs (one environment per lane, identical in both lane
 // halves).  On return every lane holds its environment's V and (if want_grad) gradient.
-template <typename S, int TL>
+template <typename S, int TL, int ACT = HJBX_ACT_RELU>
 __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p, const MlpCtx& c, const float (&xs)[TL][S::N],
                                                bool want_grad, float (&V)[TL], float (&g)[TL][S::N]) {
     constexpr int N = S::N;
@@ -235,7 +254,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[t][fb][r] = relu1(a1[t][fb][r]);
+            for (int r = 0; r < 16; ++r) a1[t][fb][r] = act1<ACT>(a1[t][fb][r]);
     f32x16 a2[TL][4];
     zero_acc(a2);
     mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, c.w2f, [&](int st, int t) { return a1[t][st >> 4][st & 15]; });
@@ -246,7 +265,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a2[t][fb][r] = relu1(a2[t][fb][r]);  // relu(a) > 0 <=> a > 0: still the mask for backward 2
+            for (int r = 0; r < 16; ++r) a2[t][fb][r] = act1<ACT>(a2[t][fb][r]);  // the activation also carries act' for backward 2 (dact1)
     f32x16 y[TL][2];
     zero_acc(y);
     mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, c.w3f, [&](int st, int t) { return a2[t][st >> 4][st & 15]; });
@@ -277,7 +296,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2[t][fb][r] = a2[t][fb][r] > 0.f ? d2[t][fb][r] : 0.f;
+            for (int r = 0; r < 16; ++r) d2[t][fb][r] = dact1<ACT>(a2[t][fb][r], d2[t][fb][r]);
     f32x16 d1[TL][4];
     zero_acc(d1);
     mfma_chain<OffW2B, 64, 4, 2, TL>(d1, ring4, c.w2b, [&](int st, int t) { return d2[t][st >> 4][st & 15]; });
@@ -298,7 +317,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const float dv = a1[t][kb][s] > 0.f ? d1[t][kb][s] : 0.f;
+                const float dv = dact1<ACT>(ACT == HJBX_ACT_RELU ? a1[t][kb][s] : act1<ACT>(a1[t][kb][s]), d1[t][kb][s]);
                 const f32x2 dv2{dv, dv};
 #pragma unroll
                 for (int q = 0; q < NP / 4; ++q) {
@@ -350,7 +369,7 @@ template <int N> __device__ __forceinline__ void store_row(float* __restrict__ o
 }
 
 // ---- kernel 1: V and dV/dx for a batch of states (hjbx_value_grad_f32) ---------------------------------------
-template <typename S, int TL, int WAVES>
+template <typename S, int TL, int WAVES, int ACT>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
                                                                          const float* __restrict__ W2g, const float* __restrict__ W3g,
                                                                          const float* __restrict__ x, float* __restrict__ Vout,
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
         load_rows(grp_next, xn);
 
         float V[TL], g[TL][N];
-        mlp_value_grad<S, TL>(sys, p, c, xs, gout != nullptr, V, g);
+        mlp_value_grad<S, TL, ACT>(sys, p, c, xs, gout != nullptr, V, g);
 #pragma unroll
         for (int t = 0; t < TL; ++t) {
             const int64_t env = (grp * TL + t) * 32 + i;
@@ -450,7 +469,7 @@ template <int N, int M> struct RolloutOut {
     float* x_out;  // (B, N) or NULL
 };
 
-template <int INTEG, typename S, int WAVES>
+template <int INTEG, typename S, int WAVES, int ACT>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
                                                                            Limits<float, S::M> lim_k, const float* __restrict__ W1g,
                                                                            const float* __restrict__ W2g, const float* __restrict__ W3g,
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
                 cst = dn = res = 0.0f;
             } else {
                 float V[1], g[1][N];
-                mlp_value_grad<S, 1>(sys, p, c, xs, true, V, g);
+                mlp_value_grad<S, 1, ACT>(sys, p, c, xs, true, V, g);
                 vhjb_step_env<INTEG>(sys, tk, lim, t_first + k, T_max, o.resid != nullptr, xs[0], g[0], ds, xo, u, cst, dn, res);
             }
             if (writer) {
@@ -542,6 +561,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     }
 }
 
+static int check_activation(const hjbx_mlp* mlp, const char* who) {
+    if (mlp->activation == HJBX_ACT_RELU || mlp->activation == HJBX_ACT_TANH) return HJBX_OK;
+    if (mlp->activation == HJBX_ACT_SIN)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "%s: no fused kernel for the sin activation (its derivative needs the pre-activations)", who);
+    return hjbx_set_error(HJBX_EINVAL, "%s: unknown activation %d", who, mlp->activation);
+}
+
 template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* st) {
     constexpr int N = S::N;
     constexpr int TL = HJBX_MLP_TL, WAVES = HJBX_MLP_WAVES;
@@ -560,8 +586,12 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
     // one resident workgroup per CU (106 KB of LDS each); small batches are spread one tile group per CU
     // rather than packed eight to a workgroup, so up to n_cu matrix pipes work on them
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;
-    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
-                       (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
+    if (mlp->activation == HJBX_ACT_TANH)
+        hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, HJBX_ACT_TANH>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
+                           (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
+    else
+        hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, HJBX_ACT_RELU>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
+                           (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_grad_f32: %s", hipGetErrorString(e));
     return HJBX_OK;
@@ -576,6 +606,7 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
     if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2,
                               mlp->h3);
+    if (int rc = check_activation(mlp, "hjbx_value_grad_f32")) return rc;
     const size_t row = (size_t)sys->n * sizeof(float);
     const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
     if ((reinterpret_cast<uintptr_t>(x) & am) || (g && (reinterpret_cast<uintptr_t>(g) & am)))
@@ -622,15 +653,17 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     }
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;  // as in launch_value_grad
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
-    if (integrator == HJBX_EULER)
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
-                           W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
-    else if (integrator == HJBX_RK4)
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<1, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
-                           W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
-    else if constexpr (S::kHasZoh)
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<2, S, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p, tk, lim, W1,
-                           W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
+    auto launch = [&](auto integ, auto act) {
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, decltype(act)::value>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
+                           (hipStream_t)st, sys, p, tk, lim, W1, W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
+    };
+    auto with_act = [&](auto integ) {
+        if (mlp->activation == HJBX_ACT_TANH) launch(integ, std::integral_constant<int, HJBX_ACT_TANH>{});
+        else launch(integ, std::integral_constant<int, HJBX_ACT_RELU>{});
+    };
+    if (integrator == HJBX_EULER) with_act(std::integral_constant<int, 0>{});
+    else if (integrator == HJBX_RK4) with_act(std::integral_constant<int, 1>{});
+    else if constexpr (S::kHasZoh) with_act(std::integral_constant<int, 2>{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_vhjb_rollout_f32: %s", hipGetErrorString(e));
     return HJBX_OK;
@@ -649,6 +682,7 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
     if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2,
                               mlp->h3);
+    if (int rc = check_activation(mlp, "hjbx_vhjb_rollout_f32")) return rc;
     const size_t row = (size_t)sys->n * sizeof(float);
     const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
     const size_t urow = (size_t)sys->m * sizeof(float);

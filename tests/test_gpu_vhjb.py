@@ -29,7 +29,7 @@ def controller(name, dtype=torch.float32, **kw):
 def oracle_mlp(ctl):
     vf = ctl.value_function_approximator
     W = [w.detach().cpu().numpy().astype(np.float64) for w in vf.weights]
-    return O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar), W
+    return O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar, activation=vf.activation), W
 
 
 def states_near_target(d, ctl, B, seed, scale=1.0, dtype=torch.float32):
@@ -484,3 +484,66 @@ def test_compaction_makes_finished_environments_cheap():
     assert torch.equal(o_nat["cost"], o_packed["cost"]) and torch.equal(o_nat["x_out"], o_packed["x_out"]) and torch.equal(ds_nat, ds_packed)
     print(f"16 steps, 2^20 environments, 1/8 live: natural order {t_nat:.2f} ms, live-first {t_packed:.2f} ms")
     assert t_packed < 0.3 * t_nat
+
+
+@pytest.mark.parametrize("B", [33, 5000])
+@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
+def test_tanh_network_fused_kernels_vs_oracle_and_torch(name, B):
+    """hjbx_mlp.activation = HJBX_ACT_TANH (the network of examples/cartpole_balancing.ipynb cell 6): the fused value-gradient
+    kernel against the f64 oracle (exact tanh) and against the PyTorch graph, and the fused rollout kernel bit-identical to
+    value_grad + vhjb_step step by step.  The kernel's tanh is 1 - 2/(exp(2x)+1) on the exp2 / rcp units (abs err ~1e-7)."""
+    d, ctl = controller(name, torch.float32, activation="tanh")
+    assert ctl.fused_value_grad
+    vf = ctl.value_function_approximator
+    with torch.no_grad():
+        for w in vf.weights:
+            w.mul_(1.7)                                          # push part of the units towards saturation
+    x = states_near_target(d, ctl, B, 2, 1.5)
+    V, g = vf.fused_value_grad(x)
+    mlp, W = oracle_mlp(ctl)
+    oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
+    sv, sg = np.abs(oV).max(), np.abs(og).max()
+    assert np.abs(V.cpu().numpy() - oV).max() <= 3e-5 * sv, np.abs(V.cpu().numpy() - oV).max() / sv
+    assert np.abs(g.cpu().numpy() - og).max() <= 3e-5 * sg, np.abs(g.cpu().numpy() - og).max() / sg
+    with torch.no_grad():
+        tV, tg = vf.value_and_grad(x)
+    assert float((tV - V).abs().max()) <= 3e-5 * sv and float((tg - g).abs().max()) <= 3e-5 * sg
+    # fused rollout == stepwise, and both follow the oracle's loop
+    T = 10
+    x0 = states_near_target(d, ctl, B, 8, 1.03)
+    n, m = d.get_dimension()
+    traj = torch.empty((T + 2, B, n), device="cuda"); cost = torch.empty((T + 1, B), device="cuda"); done = torch.empty_like(cost)
+    ds = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    traj[0].copy_(x0)
+    for t in range(T + 1):
+        gg = vf.fused_value_grad(traj[t], want_v=False)[1]
+        _ops.vhjb_step(d.system, ctl._task, t, T, traj[t], gg, traj[t + 1], cost[t], done[t], ds)
+    ds1 = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    one = _ops.vhjb_rollout(d.system, ctl._task, vf.descriptor(), x0, T + 1, T, ds1)
+    assert torch.equal(ds1, ds) and torch.equal(one["traj"], traj) and torch.equal(one["cost"], cost) and torch.equal(one["done"], done)
+    ref = O.vhjb_rollout(O.System.from_dynamics(d), ctl._task, mlp, *W, x0.cpu().numpy().astype(np.float64), T)
+    keep = ds.cpu().numpy() == ref["done_step"]
+    assert keep.mean() > 0.97
+    err = np.abs(wrapped_diff(traj[:T + 1].cpu().numpy().astype(np.float64), ref["traj"], ANGLE_IDX[name]))[:, keep]
+    scale = max(1.0, np.abs(ref["traj"]).max())
+    # a random, high-gain tanh policy is a chaotic closed loop: fp32 rounding is amplified step by step in a few of the
+    # environments, so the pin is tight on the first steps and statistical on the whole horizon
+    assert err[:4].max() < 2e-3 * scale, err[:4].max()
+    assert np.quantile(err.max(axis=(0, 2)), 0.99) < 2e-3 * scale and np.median(err.max(axis=(0, 2))) < 1e-4 * scale
+
+
+def test_sin_network_has_no_fused_kernel():
+    d, ctl = controller("cartpole", torch.float32, activation="sin")
+    assert not ctl.fused_value_grad
+    vf = ctl.value_function_approximator
+    x = states_near_target(d, ctl, 64, 2, 1.0)
+    with pytest.raises(NotImplementedError):
+        vf.fused_value_grad(x)
+    with pytest.raises(NotImplementedError, match="sin"):
+        _ops.value_grad(d.system, vf.descriptor(), x, True, True)
+    # the PyTorch path agrees with the oracle's sin / cos
+    mlp, W = oracle_mlp(ctl)
+    with torch.no_grad():
+        V, g = vf.value_and_grad(x)
+    oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
+    assert np.abs(V.cpu().numpy() - oV).max() <= 3e-5 * np.abs(oV).max() and np.abs(g.cpu().numpy() - og).max() <= 3e-5 * np.abs(og).max()
