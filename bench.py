@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--system", default="cartpole", choices=["cartpole", "acrobot", "quad2d", "nearhover", "linear"],
                     help="default cartpole = BASELINE configs[1]; quad2d / nearhover = the VHJB loops of configs[3] / configs[4]")
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"], help="euler = the reference's integrator (parity mode)")
+    ap.add_argument("--activation", default="relu", choices=["relu", "tanh"], help="relu = controller/vhjb.py (the BASELINE workload); tanh = the cartpole notebook's network")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--torch-mlp", action="store_true", help="value gradient through PyTorch matmuls instead of the fused kernel")
@@ -94,7 +95,7 @@ def main():
     }[args.system]()
     if args.integrator == "rk4":
         dyn.integrator = _abi.RK4
-    ctl = VHJBController(dyn, ccfg, fused_value_grad=not args.torch_mlp)
+    ctl = VHJBController(dyn, ccfg, fused_value_grad=not args.torch_mlp, activation=args.activation)
     vf = ctl.value_function_approximator
     wgen = torch.Generator(device="cuda"); wgen.manual_seed(1234)
     vf.load_quadratic(ctl.P, noise=0.05, generator=wgen)
@@ -236,7 +237,7 @@ def main():
                steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                data="synthetic",
                config=dict(workload=label, batch_per_gpu=B, global_batch=B * world,
-                           state_dim=n, control_dim=m, integrator=args.integrator, mlp=f"{n}-128-128-64 relu, no bias",
+                           state_dim=n, control_dim=m, integrator=args.integrator, mlp=f"{n}-128-128-64 {args.activation}, no bias",
                            value_grad=("persistent fused rollout kernel (MFMA value net + step)" if fused else
                                        "fused HIP MFMA kernel + step kernel" if ctl.fused_value_grad else "PyTorch-ROCm matmuls + step kernel"),
                            live_fraction=live / (B * world * K), parallelism=f"env-shard x{world}, no data-path collective"),
@@ -257,7 +258,7 @@ def cpu_baseline(dyn, ctl, x0, sample_envs):
     from oracle import oracle as O
     vf = ctl.value_function_approximator
     Wts = [w.detach().cpu().numpy().astype(np.float64) for w in vf.weights]
-    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar)
+    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar, activation=vf.activation)
     s = O.System.from_dynamics(dyn)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = O.threads(min(avail, 16))            # the GPU box's CPU share per GPU is 16 cores
