@@ -1,9 +1,9 @@
 // hjbx_mlp.hip -- ValueFunctionApproximator forward + input gradient (reference controller/vhjb.py:17-60
 // and get_v_gradient :201-202) fused into one gfx950 kernel on the f32 matrix cores.
 //
-//   e = wrap(x - xf); z = (e - mean)/std; h1 = relu(z W1); h2 = relu(h1 W2); y = h2 W3
+//   e = wrap(x - xf); z = (e - mean)/std; h1 = act(z W1); h2 = act(h1 W2); y = h2 W3        (act = relu | tanh)
 //   V = |y|^2 + eps_s |e|^2
-//   dV/dx = ((((2y) W3') . [h2>0]) W2' . [h1>0]) W1' / std + 2 eps_s e
+//   dV/dx = ((((2y) W3') . act'(h2)) W2' . act'(h1)) W1' / std + 2 eps_s e
 //
 // Design (CDNA4):
 //  * v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s dense peak) -- the network is float32 in the reference.
@@ -15,13 +15,16 @@
 //  * All three weight matrices live in LDS once per workgroup (106 KB, one copy serves W and W'): rows
 //    padded to an ODD stride (129 / 65 floats) so that both the row walk of the forward pass and the
 //    column walk of the backward pass hit 32 distinct banks per ds_read_b32 lane group.
-//  * Every instruction issued between two MFMAs costs matrix-pipe time here (measured ~4 cycles each,
-//    tools/ubench/mfma_mix.hip), so: weight operands are prefetched by inline-asm ds_reads two k-steps
-//    ahead and retired by counted s_waitcnt; ReLU is one integer max; the ReLU masks are not stored (the
-//    pre-activations stay in registers / layer 1 is recomputed); the last backward product (only n useful
-//    rows) runs on the VALU; and with TL = 2 each fetched weight feeds two MFMAs.
-//  * Persistent grid, one workgroup per CU; waves pull tile groups from an LDS counter so SIMD partners
-//    finish together.
+//  * A VALU-category instruction issued between two MFMAs costs matrix-pipe time (~4 cycles each, tools/ubench/mfma_mix.hip;
+//    LDS reads and s_waitcnt issue beside the MFMAs for free), so a chain is ONLY ds_read / s_waitcnt / MFMA: weight
+//    operands are prefetched by inline-asm ds_reads two k-steps ahead and retired by counted s_waitcnt; the element-wise
+//    work (activation, its derivative, |y|^2, 2y) runs in place on the accumulators in VALU-only passes between the
+//    chains, where it overlaps the SIMD partner's MFMAs; activation derivatives are taken from the activations (nothing
+//    extra is stored; layer 1 is recomputed for the last one); the last backward product (only n useful rows) runs on the
+//    VALU.  The activation is a template parameter: ReLU (one integer max) or tanh (exp2 + rcp).
+//  * Persistent grid, one workgroup per CU (2 waves per SIMD); waves pull tile groups from an LDS counter so SIMD
+//    partners finish together.  In the rollout kernel the per-environment constants (system, task, limits) are staged
+//    in LDS too: as kernel-argument SGPRs they spilled into v_readlane / v_writelane inside the chains.
 // Per environment: 4(128 n + 128*128 + 128*64) flop; algorithmic HBM traffic 4(2n+1) bytes -> MFMA bound.
 #include <hip/hip_runtime.h>
 #include <type_traits>
