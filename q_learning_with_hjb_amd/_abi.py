@@ -142,10 +142,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=on: fuse a*b+c only inside one source expression, so every kernel that inlines the same
     # device function rounds identically (fused rollout == step-by-step kernels, bit for bit)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared", "-o", _LIB_PATH] + os.environ.get("HJBX_EXTRA_FLAGS", "").split() + srcs
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC"] + os.environ.get("HJBX_EXTRA_FLAGS", "").split()
+    # the translation units compile side by side (the MFMA file alone takes ~2 minutes: 60 kernel instantiations), then link
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.splitext(src)[0] + ".o"
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return _LIB_PATH
 
 
