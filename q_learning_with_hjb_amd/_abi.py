@@ -28,7 +28,11 @@ OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
-_SOURCES = ("hjbx_kernels.hip", "hjbx_mlp.hip")
+# (source, extra flags, object): hjbx_mlp.hip is compiled once per activation (see the top of that file)
+_UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
+          ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=0",), "hjbx_mlp_relu.o"),
+          ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"))
+_SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
 _HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 
 
@@ -143,11 +147,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # -ffp-contract=on: fuse a*b+c only inside one source expression, so every kernel that inlines the same
     # device function rounds identically (fused rollout == step-by-step kernels, bit for bit)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC"] + os.environ.get("HJBX_EXTRA_FLAGS", "").split()
-    # the translation units compile side by side (the MFMA file alone takes ~2 minutes: 60 kernel instantiations), then link
+    # the translation units compile side by side (each MFMA object holds 30 kernel instantiations, ~55 s), then link
     objs, procs = [], []
-    for src in srcs:
-        obj = os.path.splitext(src)[0] + ".o"
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+    for src, extra, objname in _UNITS:
+        obj = os.path.join(_CSRC, objname)
+        cmd = [hipcc] + flags + list(extra) + ["-c", os.path.join(_CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         objs.append(obj)

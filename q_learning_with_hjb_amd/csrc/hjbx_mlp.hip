@@ -45,6 +45,25 @@ static constexpr int kLD1 = 129, kLD2 = 129, kLD3 = 65;  // odd LDS row strides 
 
 // launch shape: TL tiles of 32 environments per wave, WAVES waves per workgroup (one workgroup per CU).
 //   (TL, WAVES) = (1, 8): two waves per SIMD, 256 VGPRs each.   (2, 4): one wave per SIMD, 512 VGPRs.
+// This file is compiled once per activation (-DHJBX_MLP_ACT=0 relu, =1 tanh: 30 kernel instantiations each, side by side);
+// the relu object also carries the two C entry points, which validate and hand over to the object of the requested activation.
+#ifndef HJBX_MLP_ACT
+#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points) and again with -DHJBX_MLP_ACT=1 (tanh)"
+#endif
+static constexpr int kAct = HJBX_MLP_ACT;
+static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH, "fused kernels exist for relu and tanh");
+#define HJBX_MLP_CAT2(a, b) a##b
+#define HJBX_MLP_CAT(a, b) HJBX_MLP_CAT2(a, b)
+#define HJBX_MLP_SYM(name) HJBX_MLP_CAT(name, HJBX_MLP_ACT)
+#define HJBX_HIDDEN __attribute__((visibility("hidden")))
+// per-activation dispatchers (system kind -> kernel instantiation), one pair per object file
+HJBX_HIDDEN int hjbx_mlp_value_grad_act0(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_value_grad_act1(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_rollout_act0(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*);
+
 #ifndef HJBX_MLP_TL
 #define HJBX_MLP_TL 1
 #endif
@@ -564,12 +583,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     }
 }
 
+#if HJBX_MLP_ACT == 0
 static int check_activation(const hjbx_mlp* mlp, const char* who) {
     if (mlp->activation == HJBX_ACT_RELU || mlp->activation == HJBX_ACT_TANH) return HJBX_OK;
     if (mlp->activation == HJBX_ACT_SIN)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "%s: no fused kernel for the sin activation (its derivative needs the pre-activations)", who);
     return hjbx_set_error(HJBX_EINVAL, "%s: unknown activation %d", who, mlp->activation);
 }
+#endif
 
 template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* st) {
     constexpr int N = S::N;
@@ -589,33 +610,15 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
     // one resident workgroup per CU (106 KB of LDS each); small batches are spread one tile group per CU
     // rather than packed eight to a workgroup, so up to n_cu matrix pipes work on them
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;
-    if (mlp->activation == HJBX_ACT_TANH)
-        hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, HJBX_ACT_TANH>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
-                           (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
-    else
-        hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, HJBX_ACT_RELU>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
-                           (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
+    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, kAct>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
+                       (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_grad_f32: %s", hipGetErrorString(e));
     return HJBX_OK;
 }
 
-extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B,
-                                   void* stream) {
-    if (!sys || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: NULL system or mlp descriptor");
-    if (B < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: negative batch size");
-    if (B == 0 || (!V && !g)) return HJBX_OK;
-    if (!x || !mlp->W1 || !mlp->W2 || !mlp->W3) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: NULL x or weight pointer");
-    if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
-        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2,
-                              mlp->h3);
-    if (int rc = check_activation(mlp, "hjbx_value_grad_f32")) return rc;
-    const size_t row = (size_t)sys->n * sizeof(float);
-    const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
-    if ((reinterpret_cast<uintptr_t>(x) & am) || (g && (reinterpret_cast<uintptr_t>(g) & am)))
-        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: x / gradV must be aligned to their row vector width");
-    for (int k = 0; k < sys->n; ++k)
-        if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: normalization_std[%d] is zero", k);
+// system kind -> instantiation of this object's activation (arguments already validated by the C entry point)
+int HJBX_MLP_SYM(hjbx_mlp_value_grad_act)(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* stream) {
     switch (sys->kind) {
     case HJBX_SYS_LINEAR:
         if (sys->n == 2) {
@@ -632,6 +635,29 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
     }
     return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: no kernel for system kind %d with n=%d", sys->kind, sys->n);
 }
+
+
+#if HJBX_MLP_ACT == 0
+extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B,
+                                   void* stream) {
+    if (!sys || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: NULL system or mlp descriptor");
+    if (B < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: negative batch size");
+    if (B == 0 || (!V && !g)) return HJBX_OK;
+    if (!x || !mlp->W1 || !mlp->W2 || !mlp->W3) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: NULL x or weight pointer");
+    if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2,
+                              mlp->h3);
+    if (int rc = check_activation(mlp, "hjbx_value_grad_f32")) return rc;
+    const size_t row = (size_t)sys->n * sizeof(float);
+    const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
+    if ((reinterpret_cast<uintptr_t>(x) & am) || (g && (reinterpret_cast<uintptr_t>(g) & am)))
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: x / gradV must be aligned to their row vector width");
+    for (int k = 0; k < sys->n; ++k)
+        if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: normalization_std[%d] is zero", k);
+    return mlp->activation == HJBX_ACT_TANH ? hjbx_mlp_value_grad_act1(sys, mlp, x, V, g, B, stream)
+                                            : hjbx_mlp_value_grad_act0(sys, mlp, x, V, g, B, stream);
+}
+#endif
 
 template <typename S>
 static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
@@ -656,22 +682,34 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     }
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;  // as in launch_value_grad
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
-    auto launch = [&](auto integ, auto act) {
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, decltype(act)::value>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
+    auto launch = [&](auto integ) {
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, kAct>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
                            (hipStream_t)st, sys, p, tk, lim, W1, W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
     };
-    auto with_act = [&](auto integ) {
-        if (mlp->activation == HJBX_ACT_TANH) launch(integ, std::integral_constant<int, HJBX_ACT_TANH>{});
-        else launch(integ, std::integral_constant<int, HJBX_ACT_RELU>{});
-    };
-    if (integrator == HJBX_EULER) with_act(std::integral_constant<int, 0>{});
-    else if (integrator == HJBX_RK4) with_act(std::integral_constant<int, 1>{});
-    else if constexpr (S::kHasZoh) with_act(std::integral_constant<int, 2>{});
+    if (integrator == HJBX_EULER) launch(std::integral_constant<int, 0>{});
+    else if (integrator == HJBX_RK4) launch(std::integral_constant<int, 1>{});
+    else if constexpr (S::kHasZoh) launch(std::integral_constant<int, 2>{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_vhjb_rollout_f32: %s", hipGetErrorString(e));
     return HJBX_OK;
 }
 
+int HJBX_MLP_SYM(hjbx_mlp_rollout_act)(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first, int n_steps,
+                                       int T_max, const float* x, float* traj, float* u_log, float* cost, float* done, float* resid,
+                                       int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream) {
+    int rc = HJBX_EUNSUPPORTED;
+    const bool ok = with_system<float>(sys, [&](auto S) {
+        using SS = decltype(S);
+        if constexpr (SS::N % 2 == 0)
+            rc = launch_vhjb_rollout<SS>(sys, S, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step,
+                                         x_out, env_order, B, stream);
+    });
+    if (!ok || rc == HJBX_EUNSUPPORTED)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
+    return rc;
+}
+
+#if HJBX_MLP_ACT == 0
 extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                                      int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
                                      float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream) {
@@ -695,14 +733,8 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
         return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: x / traj / x_out / u_log must be aligned to their row vector width");
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: normalization_std[%d] is zero", k);
-    int rc = HJBX_EUNSUPPORTED;
-    const bool ok = with_system<float>(sys, [&](auto S) {
-        using SS = decltype(S);
-        if constexpr (SS::N % 2 == 0)
-            rc = launch_vhjb_rollout<SS>(sys, S, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step,
-                                         x_out, env_order, B, stream);
-    });
-    if (!ok || rc == HJBX_EUNSUPPORTED)
-        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
-    return rc;
+    return mlp->activation == HJBX_ACT_TANH
+               ? hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, stream)
+               : hjbx_mlp_rollout_act0(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, stream);
 }
+#endif

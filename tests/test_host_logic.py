@@ -252,11 +252,17 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_asm_loads
-    asm = tmp_path / "mlp.s"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S", "--cuda-device-only",
-                    "-o", str(asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_mlp.hip")], check=True,
-                   stderr=subprocess.DEVNULL)
-    assert audit_asm_loads.audit(str(asm)) == 0
+    outs, procs = [], []
+    for act in (0, 1):                                        # one object per activation, compiled side by side
+        asm = tmp_path / f"mlp_act{act}.s"
+        outs.append(asm)
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S",
+                                       "--cuda-device-only", f"-DHJBX_MLP_ACT={act}", "-o", str(asm),
+                                       os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_mlp.hip")], stderr=subprocess.DEVNULL))
+    for pr in procs:
+        assert pr.wait() == 0
+    for asm in outs:
+        assert audit_asm_loads.audit(str(asm)) == 0
     text = asm.read_text()
     assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
 

@@ -4,7 +4,7 @@
 compiler-generated instruction may touch the destination register(s) (a copy or spill there would read them before the
 data has landed).  lgkmcnt counts instructions, so a wide read is one entry.  Scans the device assembly of every kernel.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -S --cuda-device-only -o /tmp/mlp.s csrc/hjbx_mlp.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -S --cuda-device-only -DHJBX_MLP_ACT=0 -o /tmp/mlp.s csrc/hjbx_mlp.hip
     python tools/audit_asm_loads.py /tmp/mlp.s
 """
 import re
