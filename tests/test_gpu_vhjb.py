@@ -5,6 +5,8 @@ the optimiser step against an independent torch.autograd double-backward.
 controller/vhjb.py of the reference needs JAX/Flax/optax and cannot run here: these paths are PARITY
 UNPINNED against the reference itself; what is checked is agreement between independent
 restatements (C oracle, hand-derived torch graph, torch.autograd, HIP kernels) and known-answer identities."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -547,3 +549,53 @@ def test_sin_network_has_no_fused_kernel():
         V, g = vf.value_and_grad(x)
     oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
     assert np.abs(V.cpu().numpy() - oV).max() <= 3e-5 * np.abs(oV).max() and np.abs(g.cpu().numpy() - og).max() <= 3e-5 * np.abs(og).max()
+
+
+def _dp_update_worker(rank, world, port, tmp):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = torch.load(os.path.join(tmp, "dp_update.pt"))
+        d, ctl = controller("cartpole", torch.float32)
+        assert ctl.world_size == world and not ctl.graph_updates              # the data-parallel path launches eagerly
+        lo, hi = data["splits"][rank], data["splits"][rank + 1]
+        for k in range(3):
+            xs, dones, costs = (data[key][k][lo:hi].cuda() for key in ("xs", "dones", "costs"))
+            losses = ctl.params_update(xs, dones, costs, data["reg"])
+        if rank == 0:
+            torch.save(dict(W=[p.detach().cpu() for p in ctl.value_function_approximator.parameters()], losses=[float(v) for v in losses]),
+                       os.path.join(tmp, "dp_update_out.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_params_update_two_ranks_on_one_gpu(tmp_path):
+    """SURVEY 8e acceptance on the real update path: two ranks (gloo, both on cuda:0) with UNEVEN shards of each minibatch and
+    one flat all-reduce per step land on the same weights as one process on the whole minibatch (rtol 1e-5 on the update)."""
+    import torch.multiprocessing as mp
+    d, ctl = controller("cartpole", torch.float32)
+    rng = np.random.default_rng(3)
+    B = 256
+    xs = [states_near_target(d, ctl, B, 40 + k, 0.6).cpu() for k in range(3)]
+    dones = [torch.as_tensor((rng.uniform(size=B) < 0.3).astype(np.float32)) for _ in range(3)]
+    costs = [torch.as_tensor(rng.uniform(0.5, 20, B).astype(np.float32)) for _ in range(3)]
+    torch.save(dict(xs=xs, dones=dones, costs=costs, splits=[0, 100, 256], reg=0.3), tmp_path / "dp_update.pt")
+    before = [p.detach().clone() for p in ctl.value_function_approximator.parameters()]
+    for k in range(3):
+        ref_losses = ctl.params_update(xs[k].cuda(), dones[k].cuda(), costs[k].cuda(), 0.3)
+    ctx = mp.get_context("spawn")
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_dp_update_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    out = torch.load(tmp_path / "dp_update_out.pt")
+    np.testing.assert_allclose(out["losses"], [float(v) for v in ref_losses], rtol=2e-4)
+    for w_dp, w_ref, w0 in zip(out["W"], ctl.value_function_approximator.parameters(), before):
+        step = (w_ref.detach().cpu() - w0.cpu())
+        diff = (w_dp - w_ref.detach().cpu()).abs().max()
+        assert float(diff) <= 0.05 * float(step.abs().max()) + 1e-7, (float(diff), float(step.abs().max()))
