@@ -4,11 +4,12 @@
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_phase tools/ubench/mfma_phase.hip && ./mfma_phase
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <int CH, int VN, int MODE> __global__ __launch_bounds__(512) void k(float* out, unsigned long long* stamps, int iters, const float* src) {
+template <int CH, int VN, int MODE> __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* stamps, int iters, const float* src) {
     f32x16 acc[4];
     for (int a = 0; a < 4; ++a)
         for (int r = 0; r < 16; ++r) acc[a][r] = src[(threadIdx.x + r + 16 * a) & 4095];
@@ -20,7 +21,7 @@ template <int CH, int VN, int MODE> __global__ __launch_bounds__(512) void k(flo
         }
     }
     if (MODE == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the second wave
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // one 100 MHz counter for the whole chip
     for (int it = 0; it < iters; ++it) {
         if (MODE == 3) __builtin_amdgcn_s_setprio(0);
         if (MODE == 4) __builtin_amdgcn_s_setprio(3);  // chains run at raised priority: a ready MFMA wins the issue port
@@ -37,32 +38,44 @@ template <int CH, int VN, int MODE> __global__ __launch_bounds__(512) void k(flo
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
     for (int a = 0; a < 4; ++a)
         for (int r = 0; r < 16; ++r) s += acc[a][r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        stamps[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)] = t0;
+        stamps[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) + 1] = t1;
+    }
 }
 
 static double g_ref = 0;  // s_memtime ticks per MFMA of the pure stream (== 64 core cycles)
 template <int CH, int VN, int MODE> void run(int threads, const char* tag) {
-    const int blocks = 256, iters = 40000 / CH;
+    const int blocks = 256, iters = 400000 / CH;
     float *out, *src;
     unsigned long long* st;
     hipMalloc(&out, blocks * threads * 4);
-    hipMalloc(&st, blocks * (threads / 64) * 8);
+    hipMalloc(&st, blocks * (threads / 64) * 16);
     hipMalloc(&src, 4096 * 4);
     std::vector<float> hs(4096);
     for (int i = 0; i < 4096; ++i) hs[i] = (i % 7) - 3.0f;
     hipMemcpy(src, hs.data(), 4096 * 4, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<CH, VN, MODE>), dim3(blocks), dim3(threads), 0, 0, out, st, iters, src);
     hipDeviceSynchronize();
-    std::vector<unsigned long long> h(blocks * (threads / 64));
+    const int wpb = threads / 64;
+    std::vector<unsigned long long> h(2 * blocks * wpb);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    // per workgroup (= CU): span from the first wave's start to the last wave's end, against the MFMAs each SIMD issued
     double sum = 0;
-    for (auto v : h) sum += (double)v;
-    const double ticks = sum / h.size() / ((double)iters * CH) / (threads / 256);
+    for (int b = 0; b < blocks; ++b) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int w = 0; w < wpb; ++w) {
+            lo = std::min(lo, h[2 * (b * wpb + w)]);
+            hi = std::max(hi, h[2 * (b * wpb + w) + 1]);
+        }
+        sum += (double)(hi - lo);
+    }
+    const double ticks = sum / blocks / ((double)iters * CH * (threads / 256));   // 100 MHz ticks per MFMA per SIMD
     if (g_ref == 0) g_ref = ticks;
     printf("%-34s CH=%4d VALU=%4d  %d waves/SIMD: %6.1f cycles per MFMA per SIMD  (pipe busy %.1f %%)\n", tag, CH, 2 * VN, threads / 256,
            64.0 * ticks / g_ref, 100.0 * g_ref / ticks);
@@ -73,6 +86,11 @@ int main() {
     run<256, 0, 0>(256, "pure MFMA (reference)");
     run<256, 0, 0>(512, "pure MFMA");
     for (int t : {256, 512}) {
+        run<256, 64, 0>(t, "chain + VALU");
+        run<256, 256, 0>(t, "chain + VALU");
+        run<128, 256, 0>(t, "chain + VALU");
+    }
+    for (int t : {768, 1024}) {   // three / four waves per SIMD: does a third wave hide the VALU phases better?
         run<256, 64, 0>(t, "chain + VALU");
         run<256, 256, 0>(t, "chain + VALU");
         run<128, 256, 0>(t, "chain + VALU");
