@@ -102,7 +102,10 @@ template <int ACT> __device__ __forceinline__ float act1(float v) {
 }
 template <int ACT> __device__ __forceinline__ float dact1(float h, float d) {
     if constexpr (ACT == HJBX_ACT_TANH) return d - d * h * h;
-    else return h > 0.f ? d : 0.f;
+    // relu: d * [h > 0] as two multiplies, the first with the clamp output modifier (v_mul_f32 ... clamp gives exactly 1 for
+    // every normal h > 0, and 0 for h <= 0 or NaN).  Same op count as v_cmp + v_cndmask, but no VCC in between: that pair
+    // costs an s_nop per element (VALU write of VCC -> VALU read), 192 of them per tile and step.
+    else return d * fminf(fmaxf(h * 3.0e38f, 0.f), 1.f);
 }
 
 // ---- software-pipelined MFMA chain ------------------------------------------------------------------------
@@ -295,14 +298,18 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
     float vpart[TL];
 #pragma unroll
     for (int t = 0; t < TL; ++t) {
-        vpart[t] = 0.f;
+        f32x2 acc2{0.f, 0.f};  // packed: one v_pk_fma_f32 and one v_pk_add_f32 per two outputs
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                vpart[t] += y[t][ob][r] * y[t][ob][r];
-                y[t][ob][r] = 2.f * y[t][ob][r];  // dV/dy
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 yy{y[t][ob][r], y[t][ob][r + 1]};
+                acc2 = __builtin_elementwise_fma(yy, yy, acc2);
+                const f32x2 y2 = yy + yy;  // dV/dy
+                y[t][ob][r] = y2[0];
+                y[t][ob][r + 1] = y2[1];
             }
+        vpart[t] = acc2[0] + acc2[1];
         V[t] = vpart[t] + __shfl_xor(vpart[t], 32, 64) + p.eps_s * ee[t];
     }
     if (!want_grad) return;
@@ -509,8 +516,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     __shared__ TaskP<float, N, M> tk_s;
     __shared__ Limits<float, M> lim_s;
     const int tid = threadIdx.x;
+    // One queue per SIMD (the waves w and w + 4 of a workgroup share SIMD w & 3): SIMD q works through the picks q, q + 4, q + 8, ...
+    // of this workgroup.  A tile here is a whole n_steps-step rollout, so with a single queue per workgroup the four SIMDs of a
+    // CU could end up with 9 / 7 tiles instead of 8 / 8 at B = 2^18 and the CU waited for the unlucky one (+-12 % from build to build).
+    __shared__ int q_next[4];
+    if (tid < 4) q_next[tid] = WAVES / 4;
     if (tid == 0) {
-        L.next = WAVES;
         sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k;
     }
     mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
@@ -527,7 +538,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     // so the groups are dealt round-robin (group = blockIdx + k gridDim) to spread the live tiles over all CUs.
     const int64_t groups_per_wg = (ngroups + gridDim.x - 1) / gridDim.x;
     const int64_t g_begin = (int64_t)blockIdx.x * groups_per_wg;
-    for (int64_t pick = wave;;) {
+    const int simd = wave & 3;
+    for (int64_t pick = wave;;) {   // wave = simd + 4 * (wave >> 2): the first WAVES / 4 picks of each SIMD are taken statically
         const int64_t grp = order ? (int64_t)blockIdx.x + pick * (int64_t)gridDim.x : g_begin + pick;
         if (grp >= ngroups || (!order && pick >= groups_per_wg)) break;
         const int64_t slot = grp * 32 + i;
@@ -578,8 +590,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
             if (o.x_out) store_row<N>(o.x_out, env, xs[0]);
         }
         int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(&L.next, 1);
-        pick = __builtin_amdgcn_readfirstlane(nxt);
+        if (lane == 0) nxt = atomicAdd(&q_next[simd], 1);
+        pick = simd + 4 * (int64_t)__builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
