@@ -71,7 +71,9 @@ HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, cons
 #define HJBX_MLP_WAVES 8
 #endif
 
-template <int N> struct MlpP { float mean[N], std[N], xf[N], eps_s; };
+// istd = 1 / normalization_std, rounded once on the host: the kernels multiply (an IEEE division is ~10 VALU instructions, 2N of
+// them per tile and step otherwise)
+template <int N> struct MlpP { float mean[N], istd[N], xf[N], eps_s; };
 
 // accumulator register s of lane-half h holds row perm(s) + 4h of its 32-row block
 __device__ __forceinline__ constexpr int perm(int s) { return (s & 3) + 8 * (s >> 2); }
@@ -258,7 +260,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             ee[t] += e[t][k] * e[t][k];
-            z[t][k] = (e[t][k] - p.mean[k]) / p.std[k];
+            z[t][k] = (e[t][k] - p.mean[k]) * p.istd[k];
         }
     }
     float ring4[3][4], ring2[3][2];  // operand rings of the chains (DEPTH = 2)
@@ -359,7 +361,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
         for (int k = 0; k < N; ++k) {
             const float pk = part[k >> 1][k & 1];
             const float v = pk + __shfl_xor(pk, 32, 64);
-            g[t][k] = v / p.std[k] + 2.f * p.eps_s * e[t][k];
+            g[t][k] = v * p.istd[k] + 2.f * p.eps_s * e[t][k];
         }
     }
 }
@@ -608,7 +610,7 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
     constexpr int N = S::N;
     constexpr int TL = HJBX_MLP_TL, WAVES = HJBX_MLP_WAVES;
     MlpP<N> p;
-    for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.std[k] = (float)mlp->std[k]; p.xf[k] = (float)mlp->xf[k]; }
+    for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.istd[k] = (float)(1.0 / mlp->std[k]); p.xf[k] = (float)mlp->xf[k]; }
     p.eps_s = (float)mlp->eps_scalar;
     const int64_t ngroups = (B + 32 * TL - 1) / (32 * TL);
     static int n_cu = 0;
@@ -678,7 +680,7 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     constexpr int N = S::N, M = S::M;
     constexpr int WAVES = HJBX_MLP_WAVES;
     MlpP<N> p;
-    for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.std[k] = (float)mlp->std[k]; p.xf[k] = (float)mlp->xf[k]; }
+    for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.istd[k] = (float)(1.0 / mlp->std[k]); p.xf[k] = (float)mlp->xf[k]; }
     p.eps_s = (float)mlp->eps_scalar;
     const auto tk = make_task<float, N, M>(task);
     const auto lim = make_limits<float, M>(sysh);
