@@ -120,7 +120,10 @@ def main():
     kernel_ms = {}
     if fused:
         # ---- the whole closed loop in persistent launches of <= CHUNK steps (hjbx_vhjb_rollout_f32) ----------------
-        CHUNK = 256
+        # launches of 100 steps: the grid is one persistent workgroup per CU with equal shares, so a CU that is briefly unavailable when a
+        # launch starts makes that launch wait for a second round (seen on shared hosts: ~2 of 60 runs came out 1.9x slow with one
+        # 200-step launch); shorter launches bound what such an event can cost, for one more launch per 200 steps (-0.3 %)
+        CHUNK = 100
         desc = vf.descriptor()
         x_cur = x0
         t = 0

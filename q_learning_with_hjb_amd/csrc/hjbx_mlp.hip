@@ -513,7 +513,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     // System, task, limits and normalisation constants are staged in LDS: as kernel arguments they are ~100-250 wave-uniform
     // scalars that do not fit the SGPR file next to the address arithmetic, and hipcc spilled them to VGPR lanes
     // (hundreds of v_readlane / v_writelane per step, some inside the MFMA chains).  LDS broadcast reads cost no SGPRs.
-    __shared__ S sys_s;
+    __shared__ __attribute__((aligned(16))) unsigned char sys_raw[sizeof(S)];  // S has default member initialisers: no __shared__ S
+    S& sys_s = *reinterpret_cast<S*>(sys_raw);
     __shared__ MlpP<N> p_s;
     __shared__ TaskP<float, N, M> tk_s;
     __shared__ Limits<float, M> lim_s;

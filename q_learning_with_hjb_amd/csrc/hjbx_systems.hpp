@@ -111,6 +111,11 @@ template <typename T> struct Cartpole {
     static constexpr bool kHasZoh = false;
     static constexpr int N = 4, M = 1;
     T mc, mp, l, g;
+    T il = T(1) / l;  // float kernels multiply by this (an IEEE division is ~10 VALU instructions); double keeps the reference's "/ l"
+    HJBX_DEV T over_l(T v) const {
+        if constexpr (sizeof(T) == 4) return v * il;
+        else return v / l;
+    }
     HJBX_DEV void wrap(T* x) const { x[1] = wrap_angle(x[1]); }
     HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
         T s, c;
@@ -120,11 +125,11 @@ template <typename T> struct Cartpole {
         f1[0] = x[2];
         f1[1] = x[3];
         f1[2] = (w + mp * g * s * c) * invD;
-        f1[3] = -(w * c + (mc + mp) * g * s) * invD / l;
+        f1[3] = over_l(-(w * c + (mc + mp) * g * s) * invD);
         f2[0] = T(0);
         f2[1] = T(0);
         f2[2] = invD;
-        f2[3] = -c * invD / l;
+        f2[3] = over_l(-c * invD);
     }
     HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
         T f1[4], f2[4];
@@ -193,6 +198,15 @@ template <typename T> struct Quad2D {
     static constexpr bool kHasZoh = false;
     static constexpr int N = 6, M = 2;
     T m, r, I, g;
+    T im = T(1) / m, rI = r / I;  // float kernels multiply by these; double keeps the reference's divisions (quadrotors.py:35-44)
+    HJBX_DEV T over_m(T v) const {
+        if constexpr (sizeof(T) == 4) return v * im;
+        else return v / m;
+    }
+    HJBX_DEV T r_over_I() const {
+        if constexpr (sizeof(T) == 4) return rI;
+        else return r / I;
+    }
     HJBX_DEV void wrap(T* x) const { x[2] = wrap_angle(x[2]); }
     HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
         T s, c;
@@ -200,18 +214,18 @@ template <typename T> struct Quad2D {
         f1[0] = x[3]; f1[1] = x[4]; f1[2] = x[5]; f1[3] = T(0); f1[4] = -g; f1[5] = T(0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) f2[i] = T(0);
-        f2[6] = -s / m; f2[7] = -s / m;
-        f2[8] = c / m;  f2[9] = c / m;
-        f2[10] = r / I; f2[11] = -r / I;
+        f2[6] = over_m(-s); f2[7] = over_m(-s);
+        f2[8] = over_m(c);  f2[9] = over_m(c);
+        f2[10] = r_over_I(); f2[11] = -r_over_I();
     }
     HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
         T s, c;
         sincos_t(x[2], &s, &c);
         // f1 + f2 @ u with f2's rows written out (same operation order as the generic affine form)
         xd[0] = x[3]; xd[1] = x[4]; xd[2] = x[5];
-        xd[3] = T(0) + ((-s / m) * u[0] + (-s / m) * u[1]);
-        xd[4] = -g + ((c / m) * u[0] + (c / m) * u[1]);
-        xd[5] = T(0) + ((r / I) * u[0] + (-r / I) * u[1]);
+        xd[3] = T(0) + (over_m(-s) * u[0] + over_m(-s) * u[1]);
+        xd[4] = -g + (over_m(c) * u[0] + over_m(c) * u[1]);
+        xd[5] = T(0) + (r_over_I() * u[0] + (-r_over_I()) * u[1]);
     }
 };
 
