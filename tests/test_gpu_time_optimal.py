@@ -178,3 +178,24 @@ def test_bad_law_is_refused():
     task = _abi.make_task(2, 1, np.eye(2), np.eye(1), None, [0, 0], [0], None, None, 0.0, law=_abi.LAW_BANGBANG, target_r2=-1.0)
     with pytest.raises(ValueError, match="target_r2"):
         _ops.control_from_grad(d.system, task, x, x)
+
+
+def test_time_optimal_graphed_update_equals_eager():
+    """The learner's optimiser step replayed from a hipGraph == eager launches (same minibatches, same initial weights)."""
+    d = _double_integrator()
+    d.integrator = _abi.ZOH
+    a = TimeOptimalVHJBController(d, activation="sin", num_states=2048, seed=5)
+    b = TimeOptimalVHJBController(d, activation="sin", num_states=2048, seed=5)
+    pa, pb = list(a.value_function_approximator.parameters()), list(b.value_function_approximator.parameters())
+    assert all(torch.equal(x, y) for x, y in zip(pa, pb)) and torch.equal(a.states, b.states)
+    start = [p.detach().clone() for p in pa]
+    for k in range(5):
+        xs = a.states[256 * k:256 * (k + 1)].contiguous()
+        la = float(a.params_update_graphed(xs))
+        lb = float(b.params_update(xs))
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb))
+    for x, y in zip(pa, pb):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-3, atol=2e-5)
+    assert all(float((p - s).abs().max()) > 1e-3 for p, s in zip(pa, start))
+    # a ragged last minibatch falls back to eager launches
+    assert np.isfinite(float(a.params_update_graphed(a.states[:100].contiguous())))
