@@ -234,6 +234,11 @@ template <typename T> struct NearHover {
     static constexpr bool kHasZoh = false;
     static constexpr int N = 10, M = 3;
     T g, m, kT, n0;
+    T kTm_f = kT / m;  // float kernels use this; double keeps the reference's division in place (quadrotors.py:143)
+    HJBX_DEV T kT_over_m() const {
+        if constexpr (sizeof(T) == 4) return kTm_f;
+        else return kT / m;
+    }
     HJBX_DEV void wrap(T* x) const { x[3] = wrap_angle(x[3]); x[4] = wrap_angle(x[4]); }
     HJBX_DEV void affine(const T* x, T* f1, T* f2) const {
 #pragma unroll
@@ -241,14 +246,14 @@ template <typename T> struct NearHover {
         f1[5] = g * tan_t(x[3]); f1[6] = g * tan_t(x[4]); f1[7] = -g; f1[8] = T(0); f1[9] = T(0);
 #pragma unroll
         for (int i = 0; i < 30; ++i) f2[i] = T(0);
-        f2[21] = kT / m; f2[25] = n0; f2[29] = n0;
+        f2[21] = kT_over_m(); f2[25] = n0; f2[29] = n0;
     }
     HJBX_DEV void xdot(const T* x, const T* u, T* xd) const {
 #pragma unroll
         for (int i = 0; i < 5; ++i) xd[i] = x[5 + i];
         xd[5] = g * tan_t(x[3]);
         xd[6] = g * tan_t(x[4]);
-        xd[7] = -g + (kT / m) * u[0];
+        xd[7] = -g + kT_over_m() * u[0];
         xd[8] = n0 * u[1];
         xd[9] = n0 * u[2];
     }
