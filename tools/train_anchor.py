@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--activation", default="relu", choices=["relu", "tanh", "sin"], help="relu = controller/vhjb.py; tanh = the notebooks")
     ap.add_argument("--notebook", action="store_true", help="the notebooks' recipe (examples/cartpole_balancing.ipynb cell 10, "
                     "drone_hovering.ipynb cell 10): data set seeded with 256 copies of xf, no boundary set, no termination loss")
+    ap.add_argument("--warm_start", type=int, default=0, help="seed the replay buffer with this many closed loops of the model-based "
+                    "controller first (BASELINE configs[2]: acrobot energy-shaping warm-start + vhjb)")
     args = ap.parse_args()
     over = {}
     if args.notebook:
@@ -39,13 +41,15 @@ def main():
     if args.notebook:      # 256 copies of xf, not a box around it
         rb = pol.replay_buffer
         rb.x[:rb.size] = torch.as_tensor(np.asarray(pol.xf, np.float64), dtype=rb.x.dtype, device=rb.x.device)
+    ws = pol.warm_start(mb, args.warm_start) if args.warm_start > 0 else None
     t0 = time.time()
     lists = pol.train()
     train_s = time.time() - t0
     np.random.seed(123)
     res = test_policy(pol, dyn, mb, T=args.T, batch=args.starts)
     cl, cm = res["cost_learned"].sum(0), res["cost_model_based"].sum(0)
-    print(json.dumps(dict(env=args.env, seed=args.seed, activation=args.activation, notebook=args.notebook, epochs=args.epochs, updates=pol.update_counter, train_seconds=round(train_s, 1),
+    print(json.dumps(dict(env=args.env, seed=args.seed, activation=args.activation, notebook=args.notebook, epochs=args.epochs,
+                          warm_start=None if ws is None else dict(records=ws["records"], average_trajectory_cost=round(ws["average_trajectory_cost"], 2)), updates=pol.update_counter, train_seconds=round(train_s, 1),
                           replay_records=len(pol.replay_buffer), avg_traj_len_first=lists[2][0], avg_traj_len_last=lists[2][-1],
                           hjb_loss_first=lists[4][0] if lists[4] else None, hjb_loss_last=lists[4][-1] if lists[4] else None,
                           mean_cost_learned=float(cl.mean()), mean_cost_model_based=float(cm.mean()),
