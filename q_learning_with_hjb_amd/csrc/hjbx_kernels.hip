@@ -265,7 +265,8 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
         error_coords(sys, tk.xf, xs, e);
         const T l = running_cost_e<S, T>(tk, e, u);
         const T den = l + tk.eps;
-        const T r = (MODE == 0) ? vdot / den + T(1) : vdot + l;
+        const T iden = T(1) / den;  // one division per environment: the gradient below would otherwise need 2 per state dimension
+        const T r = (MODE == 0) ? vdot * iden + T(1) : vdot + l;
         const T w = T(1) - dn;
         const T li = abs_t(r) * w;
         if (loss_i) loss_i[i] = li;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
                     dv += dudg * f2tg[j];
                     dl += dudg * rdu[j];
                 }
-                const T dr = (MODE == 0) ? dv / den - vdot * dl / (den * den) : dv + dl;
+                const T dr = (MODE == 0) ? dv * iden - (vdot * iden * iden) * dl : dv + dl;
                 out[k] = sg * w * dr;
             }
             RowIO<T, N>::store(dl_dg, i, out);
