@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 103 /* major*100 + minor */
+#define HJBX_VERSION 104 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -90,6 +90,15 @@ typedef enum hjbx_controller_kind {
 #define HJBX_ROLLOUT_STOP_AT_TARGET 2u /* stop an environment once e'e <= ctrl.eps_region, e = x - ctrl.xf, checked before
                                           the control of each step (time-to-origin loops of the time-optimal notebook,
                                           cell 9); done_step = index of that step */
+
+/* Process-wide tuning / test knobs (hjbx_set_option).  None of them changes results. */
+typedef enum hjbx_option {
+    HJBX_OPT_ROLLOUT_SCHEDULE = 0,         /* work distribution of hjbx_vhjb_rollout_f32: 0 (default) = equal static shares per workgroup, with
+                                              the shares of workgroups that have not started taken over by the waves that finish first;
+                                              1 = device-wide tile queue (one atomic per 32-environment tile) */
+    HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS = 1  /* TEST HOOK: launch this many workgroups more than there are CUs (they cannot be resident until
+                                              others finish -- the situation the take-over above exists for); default 0 */
+} hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */
 
@@ -151,6 +160,8 @@ int hjbx_version(void);
 size_t hjbx_last_error(char* buf, size_t buflen);
 /* Number of visible HIP devices whose arch is gfx950 (0 when there is none / no driver). */
 int hjbx_device_count(void);
+/* Sets a hjbx_option and returns its previous value (value < 0: query only); HJBX_EINVAL for an unknown option. */
+int hjbx_set_option(int option, int value);
 
 /* Replaces Dynamics.__init__ + subclass __init__ (dynamics_basic.py:17-26 etc.). */
 int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, const double* umax,
@@ -158,7 +169,10 @@ int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, co
 void hjbx_system_destroy(hjbx_system* sys);
 /* Dynamics.get_dimension, dynamics_basic.py:31-36 */
 int hjbx_dims(const hjbx_system* sys, int* n, int* m);
-/* bytes of scratch the reducing entry points need (hjb_residual, termination_residual) */
+/* Bytes of device scratch the reducing entry points need (hjb_residual, termination_residual).  The workspace holds the
+ * per-workgroup partial sums and the arrival counters of the in-kernel final reduction: it must be 16-byte aligned and ZERO-FILLED
+ * ONCE after allocation (hipMemset); every call leaves the counters at zero again, so no per-call memset is needed.  One
+ * workspace serves one stream at a time (calls on the same stream may share it; concurrent streams need one each). */
 size_t hjbx_reduce_workspace_bytes(void);
 
 #define HJBX_DECLARE(T, SFX)                                                                          \
@@ -192,8 +206,9 @@ size_t hjbx_reduce_workspace_bytes(void);
                                      const T* gradV, T* u, int64_t B, void* stream);                  \
     /* hjb_loss body (vhjb.py:227-241) forward + analytic d(loss_i)/d(gradV).           \
        done (B,) is the 0/1 mask as T.  loss_i (B,) and dloss_dgrad (B,n) may be NULL.                \
-       sums[0..2] = {sum loss_i, sum (1-done), sum done}, reduced deterministically through the       \
-       caller's workspace (>= hjbx_reduce_workspace_bytes()); sums may be NULL. */                    \
+       sums[0..2] = {sum loss_i, sum (1-done), sum done}, reduced deterministically (fixed order, no  \
+       float atomics) inside the same launch through the caller's workspace (see                      \
+       hjbx_reduce_workspace_bytes()); sums may be NULL. */                    \
     int hjbx_hjb_residual_##SFX(const hjbx_system* sys, const hjbx_task* task, int mode, const T* x,  \
                                 const T* gradV, const T* done, T* loss_i, T* dloss_dgrad, T* sums,    \
                                 void* workspace, int64_t B, void* stream);                            \
@@ -252,10 +267,15 @@ int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, const float
  *   tiles of the kernel (all arrays stay indexed by environment).  A tile whose environments have all finished skips the
  *   value network and only writes its log rows, so listing the live environments first (a stable sort by done_step >= 0,
  *   refreshed between launches) makes a batch in which most environments have terminated cost what its live part
- *   costs.  Results do not depend on the order. */
+ *   costs.  Results do not depend on the order.
+ *   x may be the same buffer as slab 0 of traj (each row is written back with the value just read).
+ *   workspace: hjbx_rollout_workspace_bytes() bytes of 16-byte aligned device memory, ZERO-FILLED ONCE after allocation; the
+ *   kernel keeps its work-distribution words there and leaves them zeroed.  One workspace per stream in flight. */
+size_t hjbx_rollout_workspace_bytes(void);
 int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                           int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
-                          float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream);
+                          float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* workspace,
+                          void* stream);
 
 #ifdef __cplusplus
 }

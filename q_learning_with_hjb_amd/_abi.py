@@ -24,6 +24,7 @@ LAW_QUADRATIC, LAW_BANGBANG = 0, 1
 ACT_RELU, ACT_TANH, ACT_SIN = 0, 1, 2
 ROLLOUT_TERMINATE = 1
 ROLLOUT_STOP_AT_TARGET = 2
+OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS = 0, 1
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -192,8 +193,8 @@ def _typed_signatures():
 
 
 EXPORTED_SYMBOLS = (
-    ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
-     "hjbx_reduce_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32"]
+    ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_set_option", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
+     "hjbx_reduce_workspace_bytes", "hjbx_rollout_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32"]
     + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
 )
 
@@ -216,6 +217,9 @@ def lib() -> C.CDLL:
         L.hjbx_last_error.argtypes = [C.c_char_p, C.c_size_t]
         L.hjbx_device_count.restype = C.c_int
         L.hjbx_reduce_workspace_bytes.restype = C.c_size_t
+        L.hjbx_rollout_workspace_bytes.restype = C.c_size_t
+        L.hjbx_set_option.restype = C.c_int
+        L.hjbx_set_option.argtypes = [C.c_int, C.c_int]
         L.hjbx_system_create.restype = C.c_int
         L.hjbx_system_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]
         L.hjbx_system_destroy.restype = None
@@ -225,7 +229,7 @@ def lib() -> C.CDLL:
         L.hjbx_value_grad_f32.restype = C.c_int
         L.hjbx_value_grad_f32.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _VP]
         L.hjbx_vhjb_rollout_f32.restype = C.c_int
-        L.hjbx_vhjb_rollout_f32.argtypes = [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
+        L.hjbx_vhjb_rollout_f32.argtypes = [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")
@@ -237,6 +241,14 @@ def lib() -> C.CDLL:
 
 class HjbxError(RuntimeError):
     pass
+
+
+def set_option(option: int, value: int) -> int:
+    """hjbx_set_option: sets a process-wide knob, returns the previous value (value < 0: query)."""
+    rc = lib().hjbx_set_option(int(option), int(value))
+    if rc < 0 and value >= 0 or rc == EINVAL:
+        check(EINVAL)
+    return rc
 
 
 def last_error() -> str:

@@ -55,8 +55,22 @@ def _workspace(device) -> torch.Tensor:
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     w = _ws.get(key)
     if w is None:
-        w = torch.empty(lib().hjbx_reduce_workspace_bytes() // 8, dtype=torch.float64, device=device)
+        # zero-filled ONCE: the reducing kernels keep their arrival counters in it and leave them at zero (include/hjbx.h)
+        w = torch.zeros((lib().hjbx_reduce_workspace_bytes() + 15) // 16 * 2, dtype=torch.float64, device=device)
         _ws[key] = w
+    return w
+
+
+_rws = {}
+
+
+def _rollout_workspace(device) -> torch.Tensor:
+    """Work-distribution words of the persistent rollout kernel: zero-filled once, left zeroed by every launch; one per stream."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    w = _rws.get(key)
+    if w is None:
+        w = torch.zeros((lib().hjbx_rollout_workspace_bytes() + 15) // 16 * 4, dtype=torch.int32, device=device)
+        _rws[key] = w
     return w
 
 
@@ -249,5 +263,5 @@ def vhjb_rollout(sys, task, mlp_desc, x, n_steps, T_max, done_step, t_first=0, i
         _chk(env_order, "env_order", (B,), torch.int32)
     check(lib().hjbx_vhjb_rollout_f32(sys.ptr, ref(task), ref(mlp_desc), int(integrator), int(t_first), int(n_steps), int(T_max), _p(x),
                                       _p(traj), _p(ulog), _p(cost), _p(done), _p(resid), _p(done_step), _p(x_out), _p(env_order), B,
-                                      _stream()))
+                                      _p(_rollout_workspace(dev)), _stream()))
     return dict(traj=traj, u=ulog, cost=cost, done=done, residual=resid, x_out=x_out)

@@ -13,3 +13,6 @@ struct hjbx_system {
 
 // records the calling thread's error message and returns `code`
 int hjbx_set_error(int code, const char* fmt, ...);
+
+// current value of a hjbx_option (hjbx_set_option), 0 for an unknown one
+int hjbx_option_value(int option);

@@ -6,6 +6,7 @@
 // algorithmic byte counts per environment are tabulated in DESIGN.md.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +31,10 @@ int hjbx_set_error(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// process-wide knobs (include/hjbx.h: hjbx_option)
+static std::atomic<int> g_options[2] = {{0}, {0}};
+int hjbx_option_value(int option) { return (option >= 0 && option < 2) ? g_options[option].load(std::memory_order_relaxed) : 0; }
 
 #define HJBX_REQUIRE(cond, ...)                                  \
     do {                                                         \
@@ -205,17 +210,31 @@ __global__ __launch_bounds__(kBlock) void k_controller(S sys, CtrlP<T, S::N, S::
 }
 
 // ----------------------------------------------------------------------------------------------
-// deterministic 3-way sum: lane partials (double) -> wave64 shuffle tree -> LDS across the 4 waves
-// -> one (3 x double) record per workgroup in the caller's workspace -> k_reduce_final sums the
-// records in index order.  No float atomics: results are bitwise reproducible run to run.
+// deterministic 3-way sum inside ONE launch: lane partials (double) -> wave64 shuffle tree -> LDS across the 4 waves
+// -> one (3 x double) record per workgroup in the caller's workspace -> the workgroup that arrives LAST sums the
+// records in index order and writes `sums`.  No float atomics and a fixed summation order: results are bitwise
+// reproducible run to run.  (Round 1 did the last stage in a second single-wave launch: 5.7 us + a kernel boundary.)
+//
+// Cross-workgroup hand-off (guide 6 G16, R1 form): the record is stored write-through (8-byte agent-scope atomic stores =
+// global_store sc1), the storing wave drains them (s_waitcnt vmcnt(0)), then ONE lane takes a ticket with a returning
+// agent-scope atomic add.  Tickets are sharded over kShards counters (each on a 128-byte line of its own; the last arriver
+// of a shard takes a ticket of the top counter): 1024 workgroups finishing together would otherwise serialise on one word
+// (~11 ns per atomic).  The last arriver issues one agent-scope acquire and reads the records with agent-scope loads.
+// The counters are left at zero by the workgroups that saw the last tickets: the workspace must be zero-filled once after
+// allocation and is zero again after every call.
 // ----------------------------------------------------------------------------------------------
+static constexpr int kShards = 32;
+static constexpr int kShardStrideWords = 32;                                           // 128 bytes per counter
+static constexpr size_t kCounterBytes = (size_t)(kShards + 1) * kShardStrideWords * 4;  // shard counters + the top counter
+#define HJBX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
 HJBX_DEV double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
 
-HJBX_DEV void block_sum3(double a, double b, double c, double* ws_record) {
+template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, unsigned char* ws, T* __restrict__ sums) {
     __shared__ double lds[3][kBlock / 64];
     a = wave_sum(a);
     b = wave_sum(b);
@@ -223,19 +242,42 @@ HJBX_DEV void block_sum3(double a, double b, double c, double* ws_record) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { lds[0][wave] = a; lds[1][wave] = b; lds[2][wave] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (wave != 0) return;
+    unsigned* cnt = reinterpret_cast<unsigned*>(ws);
+    double* rec = reinterpret_cast<double*>(ws + kCounterBytes);
+    unsigned last = 0;
+    if (lane == 0) {
         double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) { s0 += lds[0][w]; s1 += lds[1][w]; s2 += lds[2][w]; }
-        ws_record[0] = s0; ws_record[1] = s1; ws_record[2] = s2;
+        double* r = rec + 3 * (size_t)blockIdx.x;
+        __hip_atomic_store(r + 0, s0, HJBX_RLX_AGENT);
+        __hip_atomic_store(r + 1, s1, HJBX_RLX_AGENT);
+        __hip_atomic_store(r + 2, s2, HJBX_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record (and this wave's other stores) have left before the ticket is taken
+        const unsigned shard = blockIdx.x % kShards;
+        const unsigned in_shard = (gridDim.x - shard + kShards - 1) / kShards;          // workgroups with blockIdx % kShards == shard
+        unsigned* sc = cnt + shard * kShardStrideWords;
+        if (__hip_atomic_fetch_add(sc, 1u, HJBX_RLX_AGENT) == in_shard - 1) {
+            __hip_atomic_store(sc, 0u, HJBX_RLX_AGENT);                                 // every workgroup of this shard has arrived
+            unsigned* top = cnt + kShards * kShardStrideWords;
+            const unsigned nshards = gridDim.x < (unsigned)kShards ? gridDim.x : (unsigned)kShards;
+            if (__hip_atomic_fetch_add(top, 1u, HJBX_RLX_AGENT) == nshards - 1) {
+                __hip_atomic_store(top, 0u, HJBX_RLX_AGENT);
+                last = 1;
+            }
+        }
     }
-}
-
-template <typename T> __global__ __launch_bounds__(64) void k_reduce_final(const double* ws, int nrec, T* sums) {
-    double a = 0, b = 0, c = 0;
-    for (int r = threadIdx.x; r < nrec; r += 64) { a += ws[3 * r]; b += ws[3 * r + 1]; c += ws[3 * r + 2]; }
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
-    if (threadIdx.x == 0) { sums[0] = (T)a; sums[1] = (T)b; sums[2] = (T)c; }
+    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double fa = 0, fb = 0, fc = 0;
+    for (unsigned r = lane; r < gridDim.x; r += 64) {      // records in index order per lane, then the fixed shuffle tree
+        fa += __hip_atomic_load(rec + 3 * (size_t)r + 0, HJBX_RLX_AGENT);
+        fb += __hip_atomic_load(rec + 3 * (size_t)r + 1, HJBX_RLX_AGENT);
+        fc += __hip_atomic_load(rec + 3 * (size_t)r + 2, HJBX_RLX_AGENT);
+    }
+    fa = wave_sum(fa); fb = wave_sum(fb); fc = wave_sum(fc);
+    if (lane == 0) { sums[0] = (T)fa; sums[1] = (T)fb; sums[2] = (T)fc; }
 }
 
 // hjb_loss body (vhjb.py:227-241) + analytic d loss_i / d gradV
@@ -243,7 +285,7 @@ template <int MODE, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim,
                                                          const T* __restrict__ x, const T* __restrict__ g,
                                                          const T* __restrict__ done, T* __restrict__ loss_i,
-                                                         T* __restrict__ dl_dg, double* __restrict__ ws, int64_t B) {
+                                                         T* __restrict__ dl_dg, unsigned char* ws, T* __restrict__ sums, int64_t B) {
     constexpr int N = S::N, M = S::M;
     double acc_l = 0, acc_nb = 0, acc_nd = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
@@ -265,8 +307,13 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
         error_coords(sys, tk.xf, xs, e);
         const T l = running_cost_e<S, T>(tk, e, u);
         const T den = l + tk.eps;
-        const T iden = T(1) / den;  // one division per environment: the gradient below would otherwise need 2 per state dimension
-        const T r = (MODE == 0) ? vdot * iden + T(1) : vdot + l;
+        // float: one reciprocal per environment (the gradient below would otherwise need 2 divisions per state dimension);
+        // double keeps the reference's divisions in place (vhjb.py:233), like the dynamics structs do (hjbx_systems.hpp)
+        const T iden = T(1) / den;
+        T r;
+        if constexpr (MODE != 0) r = vdot + l;
+        else if constexpr (sizeof(T) == 4) r = vdot * iden + T(1);
+        else r = vdot / den + T(1);
         const T w = T(1) - dn;
         const T li = abs_t(r) * w;
         if (loss_i) loss_i[i] = li;
@@ -300,7 +347,10 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
                     dv += dudg * f2tg[j];
                     dl += dudg * rdu[j];
                 }
-                const T dr = (MODE == 0) ? dv * iden - (vdot * iden * iden) * dl : dv + dl;
+                T dr;
+                if constexpr (MODE != 0) dr = dv + dl;
+                else if constexpr (sizeof(T) == 4) dr = dv * iden - (vdot * iden * iden) * dl;
+                else dr = dv / den - vdot * dl / (den * den);
                 out[k] = sg * w * dr;
             }
             RowIO<T, N>::store(dl_dg, i, out);
@@ -309,14 +359,14 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
         acc_nb += (double)w;
         acc_nd += (double)dn;
     }
-    if (ws) block_sum3(acc_l, acc_nb, acc_nd, ws + 3 * blockIdx.x);
+    if (ws) block_sum3<T>(acc_l, acc_nb, acc_nd, ws, sums);
 }
 
 // termination_loss body (vhjb.py:243-253)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_termination_residual(T eps, const T* __restrict__ V, const T* __restrict__ cost,
                                                                  const T* __restrict__ done, T* __restrict__ loss_i,
-                                                                 T* __restrict__ dl_dV, double* __restrict__ ws, int64_t B) {
+                                                                 T* __restrict__ dl_dV, unsigned char* ws, T* __restrict__ sums, int64_t B) {
     double acc_l = 0, acc_nb = 0, acc_nd = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
         const T dn = done[i];
@@ -329,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_termination_residual(T eps, const T*
         acc_nb += 1.0 - (double)dn;
         acc_nd += (double)dn;
     }
-    if (ws) block_sum3(acc_l, acc_nb, acc_nd, ws + 3 * blockIdx.x);
+    if (ws) block_sum3<T>(acc_l, acc_nb, acc_nd, ws, sums);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -548,19 +598,18 @@ static int hjb_residual_impl(const hjbx_system* sys, const hjbx_task* task, int 
     }
     HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(done, 1); HJBX_CHECK_OPT(loss_i, 1); HJBX_CHECK_OPT(dl_dg, sys->n);
     const int grid = reduce_grid(B);
-    double* ws = sums ? (double*)workspace : nullptr;
+    unsigned char* ws = sums ? (unsigned char*)workspace : nullptr;
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto tk = make_task<T, SS::N, SS::M>(task);
             auto lim = make_limits<T, SS::M>(sys);
             if (mode == HJBX_RESIDUAL_NORMALISED)
                 hipLaunchKernelGGL((k_hjb_residual<0, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g,
-                                   done, loss_i, dl_dg, ws, B);
+                                   done, loss_i, dl_dg, ws, sums, B);
             else
                 hipLaunchKernelGGL((k_hjb_residual<1, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g,
-                                   done, loss_i, dl_dg, ws, B);
+                                   done, loss_i, dl_dg, ws, sums, B);
         })) return unsupported(sys);
-    if (sums) hipLaunchKernelGGL((k_reduce_final<T>), dim3(1), dim3(64), 0, (hipStream_t)st, ws, grid, sums);
     return check_launch("hjbx_hjb_residual");
 }
 
@@ -578,10 +627,9 @@ static int termination_residual_impl(double eps, const T* V, const T* cost, cons
     }
     HJBX_REQUIRE(V && cost && done, "V/cost/done must be non-NULL");
     const int grid = reduce_grid(B);
-    double* ws = sums ? (double*)workspace : nullptr;
+    unsigned char* ws = sums ? (unsigned char*)workspace : nullptr;
     hipLaunchKernelGGL((k_termination_residual<T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, (T)eps, V, cost, done,
-                       loss_i, dl_dV, ws, B);
-    if (sums) hipLaunchKernelGGL((k_reduce_final<T>), dim3(1), dim3(64), 0, (hipStream_t)st, ws, grid, sums);
+                       loss_i, dl_dV, ws, sums, B);
     return check_launch("hjbx_termination_residual");
 }
 
@@ -736,7 +784,14 @@ int hjbx_device_count(void) {
     return ok;
 }
 
-size_t hjbx_reduce_workspace_bytes(void) { return (size_t)kReduceBlocks * 3 * sizeof(double); }
+int hjbx_set_option(int option, int value) {
+    HJBX_REQUIRE(option == HJBX_OPT_ROLLOUT_SCHEDULE || option == HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS, "unknown option %d", option);
+    HJBX_REQUIRE(option != HJBX_OPT_ROLLOUT_SCHEDULE || value <= 1, "rollout schedule must be 0 or 1, got %d", value);
+    HJBX_REQUIRE(value <= 64, "option value %d out of range", value);
+    return value < 0 ? g_options[option].load() : g_options[option].exchange(value);
+}
+
+size_t hjbx_reduce_workspace_bytes(void) { return kCounterBytes + (size_t)kReduceBlocks * 3 * sizeof(double); }
 
 int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, const double* umax, const double* params,
                        int n_params, hjbx_system** out) {

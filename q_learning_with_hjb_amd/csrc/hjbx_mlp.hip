@@ -60,9 +60,9 @@ static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH, "fused kernels exi
 HJBX_HIDDEN int hjbx_mlp_value_grad_act0(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_value_grad_act1(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act0(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
-                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*);
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
-                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*);
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 
 #ifndef HJBX_MLP_TL
 #define HJBX_MLP_TL 1
@@ -500,13 +500,24 @@ template <int N, int M> struct RolloutOut {
     float* x_out;  // (B, N) or NULL
 };
 
+// Work distribution of the persistent rollout kernel.  The caller's workspace (hjbx_rollout_workspace_bytes(), zero-filled once,
+// left zeroed by every launch) holds, as 32-bit words:
+static constexpr int kWsQueue = 0;                      // schedule 1: head of the device-wide tile queue
+static constexpr int kWsStarted = 32;                   // workgroups that have started
+static constexpr int kWsExited = 64;                    // workgroups whose waves have all finished (the last one zeroes the workspace)
+static constexpr int kWsFlags = 96;                     // [kMaxGrid] 0 = not started, 1 = running its own range, 2 = range open to every wave
+static constexpr int kMaxGrid = 1024;
+static constexpr int kWsOpen = kWsFlags + kMaxGrid;     // [kMaxGrid] next unclaimed pick of an open range
+static constexpr int kWsWords = kWsOpen + kMaxGrid;
+#define HJBX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
 template <int INTEG, typename S, int WAVES, int ACT>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
                                                                            Limits<float, S::M> lim_k, const float* __restrict__ W1g,
                                                                            const float* __restrict__ W2g, const float* __restrict__ W3g,
-                                                                           int t_first, int n_steps, int T_max, const float* __restrict__ x,
+                                                                           int t_first, int n_steps, int T_max, const float* x /* may alias traj slab 0 */,
                                                                            const int32_t* __restrict__ order, RolloutOut<S::N, S::M> o, int64_t B,
-                                                                           int64_t ngroups) {
+                                                                           int64_t ngroups, unsigned* ws, int sched) {
     constexpr int N = S::N, M = S::M;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
     __shared__ __attribute__((aligned(16))) MlpLds<N> L;
@@ -523,8 +534,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     // of this workgroup.  A tile here is a whole n_steps-step rollout, so with a single queue per workgroup the four SIMDs of a
     // CU could end up with 9 / 7 tiles instead of 8 / 8 at B = 2^18 and the CU waited for the unlucky one (+-12 % from build to build).
     __shared__ int q_next[4];
+    __shared__ int waves_done;
+    __shared__ unsigned my_flag;
     if (tid < 4) q_next[tid] = WAVES / 4;
     if (tid == 0) {
+        waves_done = 0;
+        // announce this workgroup: 0 -> 1; a 2 coming back means the others have already opened (and taken) its range
+        unsigned seen = 0u;
+        __hip_atomic_compare_exchange_strong(ws + kWsFlags + blockIdx.x, &seen, 1u, __ATOMIC_RELAXED, HJBX_RLX_AGENT);
+        my_flag = seen;
+        __hip_atomic_fetch_add(ws + kWsStarted, 1u, HJBX_RLX_AGENT);
         sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k;
     }
     mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
@@ -536,15 +555,66 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     const int lane = tid & 63, wave = tid >> 6;
     const MlpCtx c = mlp_ctx<N>(L, lane);
     const int i = c.i, h = c.h;
-    // Natural order: each workgroup owns a contiguous range of tile groups and its waves pull from it through the LDS counter
-    // (measured 12 % faster at B = 2^18 than dealing single groups round-robin).  With `order` the live environments come first,
-    // so the groups are dealt round-robin (group = blockIdx + k gridDim) to spread the live tiles over all CUs.
-    const int64_t groups_per_wg = (ngroups + gridDim.x - 1) / gridDim.x;
-    const int64_t g_begin = (int64_t)blockIdx.x * groups_per_wg;
     const int simd = wave & 3;
-    for (int64_t pick = wave;;) {   // wave = simd + 4 * (wave >> 2): the first WAVES / 4 picks of each SIMD are taken statically
-        const int64_t grp = order ? (int64_t)blockIdx.x + pick * (int64_t)gridDim.x : g_begin + pick;
-        if (grp >= ngroups || (!order && pick >= groups_per_wg)) break;
+    const int G = (int)gridDim.x;
+    // schedule 0 (default): every workgroup owns an equal range of tile groups -- contiguous in natural order (measured 12 % faster
+    // at B = 2^18 than dealing single groups round-robin); with `order` the live environments come first, so the groups are dealt
+    // round-robin (group = workgroup + pick * gridDim) to spread the live tiles over all CUs -- and its SIMDs work through it via the
+    // LDS queues above.  A workgroup that finds no free CU when the launch starts (one workgroup fills a CU) would only run after
+    // another one has finished, doubling the launch: so a wave that has finished its own share looks for workgroups that have NOT
+    // STARTED, opens their ranges (flag 0 -> 2) and every finishing wave takes tiles from the open ranges, one returning atomic per
+    // tile; the late workgroup then finds its range taken and only helps.  With every workgroup resident this costs one atomic load.
+    // schedule 1: a device-wide queue, one returning atomic per tile (the first tile of every wave is static).
+    const int64_t picks_per_wg = (ngroups + G - 1) / G;
+    auto group_of = [&](int w, int64_t pick) -> int64_t {
+        if (pick >= picks_per_wg) return -1;
+        const int64_t g = order ? (int64_t)w + pick * G : (int64_t)w * picks_per_wg + pick;
+        return g < ngroups ? g : -1;
+    };
+    int victim = -1;                                    // schedule 0: < 0 = own range, else the workgroup whose open range is being drained
+    auto next_group = [&]() -> int64_t {
+        if (sched == 1) {
+            unsigned t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ws + kWsQueue, 1u, HJBX_RLX_AGENT);
+            const int64_t g = (int64_t)G * WAVES + (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            return g < ngroups ? g : -1;
+        }
+        if (victim < 0) {
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&q_next[simd], 1);
+            const int64_t g = my_flag == 0u ? group_of(blockIdx.x, simd + 4 * (int64_t)__builtin_amdgcn_readfirstlane(nxt)) : -1;
+            if (g >= 0) return g;
+            victim = 0;
+            unsigned started = 0;
+            if (lane == 0) started = __hip_atomic_load(ws + kWsStarted, HJBX_RLX_AGENT);
+            if (__builtin_amdgcn_readfirstlane((int)started) >= G) victim = G;     // every workgroup is resident: nothing to take over
+        }
+        while (victim < G) {
+            // flags of workgroups victim .. victim + 63; an unstarted one is opened here and now
+            const int w = victim + lane;
+            unsigned f = 1u;
+            if (w < G) {
+                f = __hip_atomic_load(ws + kWsFlags + w, HJBX_RLX_AGENT);
+                if (f == 0u && __hip_atomic_compare_exchange_strong(ws + kWsFlags + w, &f, 2u, __ATOMIC_RELAXED, HJBX_RLX_AGENT)) f = 2u;
+            }
+            unsigned long long open = __builtin_amdgcn_ballot_w64(f == 2u);
+            while (open) {
+                const int b = __builtin_ctzll(open);
+                unsigned t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(ws + kWsOpen + victim + b, 1u, HJBX_RLX_AGENT);
+                const int64_t g = group_of(victim + b, (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t));
+                if (g >= 0) { victim += b; return g; }      // (the scan resumes at this workgroup next time)
+                open &= open - 1;
+            }
+            victim = (victim + 64 < G) ? victim + 64 : G;
+        }
+        return -1;
+    };
+    int64_t grp;
+    if (sched == 1) grp = (int64_t)blockIdx.x * WAVES + wave < ngroups ? (int64_t)blockIdx.x * WAVES + wave : -1;
+    else grp = my_flag == 0u ? group_of(blockIdx.x, wave) : -1;   // wave = simd + 4 * (wave >> 2): the first WAVES / 4 picks of each SIMD are static
+    if (grp < 0) grp = next_group();
+    while (grp >= 0) {
         const int64_t slot = grp * 32 + i;
         const bool valid = slot < B;
         int64_t env = valid ? (order ? (int64_t)order[slot] : slot) : 0;
@@ -592,13 +662,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
             o.done_step[env] = ds;
             if (o.x_out) store_row<N>(o.x_out, env, xs[0]);
         }
-        int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(&q_next[simd], 1);
-        pick = simd + 4 * (int64_t)__builtin_amdgcn_readfirstlane(nxt);
+        grp = next_group();
+    }
+    // the last wave of the last workgroup leaves the workspace zeroed for the next launch
+    int lastw = 0;
+    if (lane == 0 && atomicAdd(&waves_done, 1) == WAVES - 1) lastw = __hip_atomic_fetch_add(ws + kWsExited, 1u, HJBX_RLX_AGENT) == (unsigned)(G - 1);
+    if (__builtin_amdgcn_readfirstlane(lastw)) {
+        for (int w = lane; w < kWsWords; w += 64)
+            if (w < kWsFlags || (w - kWsFlags) % kMaxGrid < G) __hip_atomic_store(ws + w, 0u, HJBX_RLX_AGENT);
     }
 }
 
 #if HJBX_MLP_ACT == 0
+extern "C" size_t hjbx_rollout_workspace_bytes(void) { return (size_t)kWsWords * sizeof(unsigned); }
 static int check_activation(const hjbx_mlp* mlp, const char* who) {
     if (mlp->activation == HJBX_ACT_RELU || mlp->activation == HJBX_ACT_TANH) return HJBX_OK;
     if (mlp->activation == HJBX_ACT_SIN)
@@ -677,7 +753,7 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
 template <typename S>
 static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                                int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done, float* resid,
-                               int32_t* done_step, float* x_out, const int32_t* order, int64_t B, void* st) {
+                               int32_t* done_step, float* x_out, const int32_t* order, int64_t B, void* workspace, void* st) {
     constexpr int N = S::N, M = S::M;
     constexpr int WAVES = HJBX_MLP_WAVES;
     MlpP<N> p;
@@ -696,10 +772,13 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;  // as in launch_value_grad
+    const int sched = hjbx_option_value(HJBX_OPT_ROLLOUT_SCHEDULE);
+    grid += hjbx_option_value(HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS);   // test hook: workgroups that cannot be resident before others finish
+    if (grid > kMaxGrid) grid = kMaxGrid;
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
     auto launch = [&](auto integ) {
         hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, kAct>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
-                           (hipStream_t)st, sys, p, tk, lim, W1, W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups);
+                           (hipStream_t)st, sys, p, tk, lim, W1, W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups, (unsigned*)workspace, sched);
     };
     if (integrator == HJBX_EULER) launch(std::integral_constant<int, 0>{});
     else if (integrator == HJBX_RK4) launch(std::integral_constant<int, 1>{});
@@ -711,13 +790,13 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
 
 int HJBX_MLP_SYM(hjbx_mlp_rollout_act)(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first, int n_steps,
                                        int T_max, const float* x, float* traj, float* u_log, float* cost, float* done, float* resid,
-                                       int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream) {
+                                       int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* workspace, void* stream) {
     int rc = HJBX_EUNSUPPORTED;
     const bool ok = with_system<float>(sys, [&](auto S) {
         using SS = decltype(S);
         if constexpr (SS::N % 2 == 0)
             rc = launch_vhjb_rollout<SS>(sys, S, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step,
-                                         x_out, env_order, B, stream);
+                                         x_out, env_order, B, workspace, stream);
     });
     if (!ok || rc == HJBX_EUNSUPPORTED)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
@@ -727,7 +806,8 @@ int HJBX_MLP_SYM(hjbx_mlp_rollout_act)(const hjbx_system* sys, const hjbx_task* 
 #if HJBX_MLP_ACT == 0
 extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int integrator, int t_first,
                                      int n_steps, int T_max, const float* x, float* traj, float* u_log, float* cost, float* done,
-                                     float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* stream) {
+                                     float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* workspace,
+                                     void* stream) {
     if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: NULL system, task or mlp descriptor");
     if (int rc = check_task(task)) return rc;
     if (B < 0 || n_steps < 0 || t_first < 0 || T_max < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: negative size or step index");
@@ -735,6 +815,8 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
     if (B == 0) return HJBX_OK;
     if (!x || !cost || !done || !done_step || !mlp->W1 || !mlp->W2 || !mlp->W3)
         return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: x, cost, done, done_step and the weights must be non-NULL");
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u))
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: workspace must be a 16-byte aligned device buffer of hjbx_rollout_workspace_bytes() zero-filled bytes");
     if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2,
                               mlp->h3);
@@ -749,7 +831,7 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: normalization_std[%d] is zero", k);
     return mlp->activation == HJBX_ACT_TANH
-               ? hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, stream)
-               : hjbx_mlp_rollout_act0(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, stream);
+               ? hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream)
+               : hjbx_mlp_rollout_act0(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
 }
 #endif

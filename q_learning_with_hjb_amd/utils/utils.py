@@ -1,15 +1,6 @@
-"""Host-side set-up helpers (reference utils/utils.py:7-14, 30-80). Not on the device path."""
+"""Host-side set-up helpers (reference utils/utils.py:30-80; its np_collate :7-14 has no counterpart: the replay buffer is device resident). Not on the device path."""
 import numpy as np
 import scipy.linalg
-
-
-def np_collate(batch):
-    """Collate for a torch DataLoader over numpy records (utils/utils.py:7-14)."""
-    if isinstance(batch[0], np.ndarray):
-        return np.stack(batch)
-    if isinstance(batch[0], (tuple, list)):
-        return [np_collate(samples) for samples in zip(*batch)]
-    return np.array(batch)
 
 
 def solve_continuous_are(A, B, Q, R):

@@ -1,0 +1,227 @@
+"""f32 parity of the kernel the headline number comes from (`k_vhjb_rollout_mfma`, hjbx_vhjb_rollout_f32) at the north-star
+tolerance, on BASELINE configs[1] / [3] / [4] at their full batch sizes.
+
+Three kinds of evidence, all against the f64 oracle fed the same float32-rounded inputs:
+
+  (i)   teacher-forced single step (n_steps = 1): per ELEMENT |got - want| <= 1e-5 |want| + atol for x', u, cost and the
+        HJB residual, with every atol written down next to its reason; max and p99.9 of err/bound are printed;
+  (ii)  integer outputs: `done_step` must be BIT-EQUAL for every environment whose f64 error coordinates keep a margin
+        > DELTA from the observation box at every step it is alive (the fraction filtered out is reported);
+  (iii) T = 200 closed loop under the LQR-embedded value network: the measured error curve max_b |x_f32 - x_f64|(t).
+
+The numbers are printed (pytest -s shows them) and written to $HJBX_REPORT_DIR/f32_parity_report.json (default gpurun_out/).
+
+controller/vhjb.py of the reference needs JAX: the oracle side of these tests is the restatement (PARITY UNPINNED).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ANGLE_IDX, ROOT, make_dynamics, make_vhjb_config, wrapped_diff
+from oracle import oracle as O
+from q_learning_with_hjb_amd import _ops
+from q_learning_with_hjb_amd.controller.vhjb import VHJBController
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5                      # BASELINE.json north_star: "trajectories matching the CPU reference to rtol 1e-5"
+DELTA = 1e-3                     # (ii): margin to the observation box, in error-coordinate units
+FULL = {"cartpole": 1 << 20, "quad2d": 1 << 18, "nearhover": 1 << 20}   # configs[1], [3], [4]
+_report = {}
+
+
+def _save_report():
+    d = os.environ.get("HJBX_REPORT_DIR", os.path.join(ROOT, "gpurun_out"))
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "f32_parity_report.json")
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_report)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def setup(name, weights):
+    d = make_dynamics(name)
+    ctl = VHJBController(d, make_vhjb_config(name), dtype=torch.float32)
+    vf = ctl.value_function_approximator
+    if weights == "lqr":       # the bench's network: LQR value function embedded exactly + 5 % dense lecun-normal noise
+        vf.load_quadratic(ctl.P, noise=0.05, generator=torch.Generator(device="cuda").manual_seed(1234))
+    W = [w.detach().cpu().numpy().astype(np.float64) for w in vf.weights]     # the oracle sees the SAME float32 weights
+    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar)
+    return d, ctl, vf, mlp, W
+
+
+def start_states(d, ctl, B, seed, frac, vel_frac=None):
+    """x0 = xf + U(-1,1) * frac * box (box = the observation box, rates capped at 3): frac < 1 starts inside it.  `vel_frac` scales
+    the second half of the state (the rates, in all five systems) separately."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    n = d.state_dim
+    box = np.asarray(ctl.obs_max, np.float64).clip(max=3.0) * frac
+    if vel_frac is not None:
+        box[n // 2:] *= vel_frac / frac
+    box = torch.as_tensor(box, dtype=torch.float32, device="cuda")
+    xf = torch.as_tensor(np.asarray(ctl.xf, np.float64), dtype=torch.float32, device="cuda")
+    u = torch.rand((B, n), generator=g, device="cuda") * 2 - 1
+    return _ops.wrap(d.system, (xf + u * box).contiguous())
+
+
+def stats(err, bound):
+    q = err / bound
+    return dict(max_err=float(err.max()), p999_err=float(np.quantile(err, 0.999)), max_ratio=float(q.max()), p999_ratio=float(np.quantile(q, 0.999)))
+
+
+@pytest.mark.parametrize("weights", ["lqr", "random"])
+@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
+def test_teacher_forced_single_step_per_element(name, weights):
+    """(i) one closed-loop step of the fused MFMA kernel from the same float32 states, full batch, per element."""
+    d, ctl, vf, mlp, W = setup(name, weights)
+    B = FULL[name]
+    n, m = d.get_dimension()
+    x = start_states(d, ctl, B, 11, 0.97)
+    ds = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    out = _ops.vhjb_rollout(d.system, ctl._task, vf.descriptor(), x, 1, 1 << 30, ds, log_traj=True, log_u=True, log_residual=True)
+    torch.cuda.synchronize()
+    s = O.System.from_dynamics(d)
+    xr = x.cpu().numpy().astype(np.float64)
+    _, g = O.value_grad(s, mlp, *W, xr)
+    oxn, ou, oc, od, ods, ors = O.vhjb_step(s, ctl._task, 0, 1 << 30, xr, g, np.full(B, -1, np.int32))
+    got_x = out["traj"][1].cpu().numpy().astype(np.float64)
+    got_u = out["u"][0].cpu().numpy().astype(np.float64)
+    got_c = out["cost"][0].cpu().numpy().astype(np.float64)
+    got_r = out["residual"][0].cpu().numpy().astype(np.float64)
+    assert np.array_equal(ds.cpu().numpy(), ods), "teacher-forced step: done_step differs"       # all start inside the box (frac < 1)
+    assert np.array_equal(out["done"][0].cpu().numpy().astype(np.float64), od)
+    live = ods < 0
+    assert live.mean() > 0.99
+
+    dt = float(d.dt)
+    umax = np.maximum(np.abs(d.umin), np.abs(d.umax)).astype(np.float64)
+    f1, f2 = O.affine(s, xr)
+    # ---- atol, per element, each with its reason -------------------------------------------------------------------------
+    # u is a point of the box [umin, umax]: atol = 1e-5 of the larger limit of that channel (170 float32 ulps of the actuator range).
+    atol_u = RTOL * umax[None, :]
+    # x'_k = x_k + dt (f1_k + sum_j f2_kj u_j): the float32 forward error is a few ulps of the largest term, and the control error
+    # allowed above enters through dt |f2_kj| atol_u_j.  atol = 1e-5 (|x_k| + dt (|f1_k| + sum_j |f2_kj| umax_j)) -- the sum of the
+    # magnitudes of the terms of that very element, nothing batch-wide.
+    terms_x = np.abs(xr) + dt * (np.abs(f1) + np.einsum("bkj,j->bk", np.abs(f2), umax))
+    atol_x = RTOL * terms_x
+    # cost = dt (e'Qe + du'R du): a sum of non-negative terms for the diagonal Q, R of these configs, so relative accuracy holds except
+    # for what the allowed control error contributes: d cost = 2 dt |R du| atol_u.  atol = that + 1e-5 dt (one cost unit x dt).
+    du = ou - np.asarray(ctl.uf, np.float64)[None, :]
+    R = np.asarray(ctl.R, np.float64).reshape(m, m)
+    atol_c = 2 * dt * np.einsum("bj,j->b", np.abs(du @ R.T), atol_u[0]) + RTOL * dt
+    # residual r = gradV . xdot / (l + eps) + 1: gradV . xdot cancels (it is ~ -l near the optimum), so its error scale is the sum of the
+    # magnitudes of its terms divided by (l + eps): atol = 1e-5 (1 + sum_k |g_k xdot_k| / (l + eps)), per element.
+    xd = O.dynamics_step(s, xr, ou)
+    l = oc / dt
+    atol_r = RTOL * (1.0 + np.abs(g * xd).sum(1) / (l + float(ctl.epsilon)))
+
+    ai = ANGLE_IDX[name]
+    ex = np.abs(wrapped_diff(got_x, oxn, ai))[live]
+    bx = (RTOL * np.abs(oxn) + atol_x)[live]
+    eu = np.abs(got_u - ou)[live]
+    bu = (RTOL * np.abs(ou) + atol_u)[live]
+    ec = np.abs(got_c - oc)[live]
+    bc = (RTOL * np.abs(oc) + atol_c)[live]
+    er = np.abs(got_r - ors)[live]
+    br = (RTOL * np.abs(ors) + atol_r)[live]
+    rep = dict(B=B, x_next=stats(ex, bx), u=stats(eu, bu), cost=stats(ec, bc), residual=stats(er, br),
+               rel_err_x_next_max=float((ex / np.maximum(np.abs(oxn[live]), 1e-30)).max()),
+               gradV_abs_max=float(np.abs(g).max()))
+    _report[f"teacher_forced/{name}/{weights}"] = rep
+    _save_report()
+    print(f"\n[f32 parity (i)] {name} {weights} B={B}: " + "; ".join(
+        f"{k}: max err {v['max_err']:.2e}, p99.9 {v['p999_err']:.2e}, max err/bound {v['max_ratio']:.3f}" for k, v in rep.items() if isinstance(v, dict)))
+    assert (ex <= bx).all(), f"x': {(ex > bx).mean():.2e} of the elements beyond 1e-5|want| + atol (max ratio {(ex / bx).max():.2f})"
+    assert (eu <= bu).all(), f"u: {(eu > bu).mean():.2e} beyond the bound (max ratio {(eu / bu).max():.2f})"
+    assert (ec <= bc).all(), f"cost: {(ec > bc).mean():.2e} beyond the bound (max ratio {(ec / bc).max():.2f})"
+    assert (er <= br).all(), f"residual: {(er > br).mean():.2e} beyond the bound (max ratio {(er / br).max():.2f})"
+
+
+def _margins(s, task_cfg, traj, ai):
+    """min over coordinates of the distance of wrap(x - xf) to the observation box faces, per (t, env); negative = outside."""
+    T1, B, n = traj.shape
+    xf = np.asarray(task_cfg.xf, np.float64)
+    e = O.wrap(s, (traj.reshape(-1, n) - xf[None, :])).reshape(T1, B, n)
+    omin, omax = np.asarray(task_cfg.obs_min, np.float64), np.asarray(task_cfg.obs_max, np.float64)
+    return np.minimum(omax[None, None, :] - e, e - omin[None, None, :]).min(-1)
+
+
+@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
+def test_done_step_bit_equal_outside_margin(name):
+    """(ii) `done_step` of the fused rollout == the f64 oracle's, bit for bit, for every environment that never comes within DELTA of
+    a face of the observation box while alive (an environment inside that band can legitimately cross one step apart in float32)."""
+    d, ctl, vf, mlp, W = setup(name, "lqr")
+    B, T = FULL[name], 30
+    x0 = start_states(d, ctl, B, 12, 1.04, vel_frac=0.3)    # some start outside the box, more leave during the 30 steps
+    out = ctl.rollout_batch(x0, max_steps=T)
+    torch.cuda.synchronize()
+    s = O.System.from_dynamics(d)
+    ref = O.vhjb_rollout(s, ctl._task, mlp, *W, x0.cpu().numpy().astype(np.float64), T)
+    ds, rs = out["done_step"].cpu().numpy(), ref["done_step"]
+    mg = _margins(s, ctl, ref["traj"], ANGLE_IDX[name])                     # (T+1, B)
+    alive = np.arange(T + 1)[:, None] <= rs[None, :]                       # steps at which the env's box test is evaluated
+    near = ((np.abs(mg) <= DELTA) & alive).any(0)
+    safe = ~near
+    n_term = int((rs < T).sum())
+    rep = dict(B=B, T=T, delta=DELTA, filtered_fraction=float(near.mean()), terminated_before_T=n_term / B,
+               mismatches_in_safe=int((ds[safe] != rs[safe]).sum()), mismatches_in_band=int((ds[near] != rs[near]).sum()))
+    _report[f"done_step/{name}"] = rep
+    _save_report()
+    print(f"\n[f32 parity (ii)] {name} B={B} T={T}: {near.mean():.3%} of the environments within {DELTA:g} of a box face (filtered), "
+          f"{n_term / B:.1%} terminate before T; mismatches: {rep['mismatches_in_safe']} outside the band, {rep['mismatches_in_band']} inside")
+    assert 0.02 < n_term / B < 0.98, "the test needs both terminating and surviving environments"
+    assert near.mean() < 0.02, "the margin band should filter out only a small fraction"
+    assert np.array_equal(ds[safe], rs[safe]), f"{(ds[safe] != rs[safe]).sum()} done_step mismatches outside the margin band"
+    # the float32 trajectories of the agreeing environments stay well inside the band width
+    tr = out["traj"].cpu().numpy().astype(np.float64)
+    err = np.abs(wrapped_diff(tr, ref["traj"], ANGLE_IDX[name]))[:, safe].max(-1)          # (T+1, safe)
+    err = np.where(alive[:, safe], err, 0.0)
+    assert err.max() < DELTA / 4, f"float32 drift {err.max():.2e} is not small against the margin {DELTA:g}"
+
+
+@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
+def test_closed_loop_error_curve_T200(name):
+    """(iii) 200 closed-loop steps (the reference's maximum_step) under the LQR-embedded value network, B = 2^16: error curve of the
+    fused float32 rollout against the f64 oracle from the same float32 start states.  The loop is stabilised, so rounding
+    errors contract instead of growing: the bound asserted is 1e-5 of each coordinate's range plus 1e-5 |x|, at EVERY step."""
+    d, ctl, vf, mlp, W = setup(name, "lqr")
+    B, T = 1 << 16, 200
+    x0 = start_states(d, ctl, B, 13, 0.5)
+    out = ctl.rollout_batch(x0, max_steps=T)
+    torch.cuda.synchronize()
+    s = O.System.from_dynamics(d)
+    ref = O.vhjb_rollout(s, ctl._task, mlp, *W, x0.cpu().numpy().astype(np.float64), T)
+    ds, rs = out["done_step"].cpu().numpy(), ref["done_step"]
+    same = ds == rs
+    tr = out["traj"].cpu().numpy().astype(np.float64)
+    err = np.abs(wrapped_diff(tr, ref["traj"], ANGLE_IDX[name]))            # (T+1, B, n)
+    rng_k = np.abs(ref["traj"]).reshape(-1, d.state_dim).max(0)             # per-coordinate range over the whole run
+    bound = RTOL * np.abs(ref["traj"]) + RTOL * np.maximum(rng_k, 1.0)[None, None, :]
+    ratio = (err / bound)[:, same]
+    curve_t = [1, 2, 5, 10, 20, 50, 100, 150, 200]
+    curve = {str(t): dict(max_abs=float(err[t][same].max()), p999_abs=float(np.quantile(err[t][same], 0.999)), max_ratio=float(ratio[t].max()))
+             for t in curve_t}
+    cerr = np.abs(out["cost"].cpu().numpy().astype(np.float64) - ref["cost"])[:, same]
+    tot_g = (out["cost"].double() * (torch.arange(T + 1, device="cuda")[:, None] <= out["done_step"][None, :])).sum(0).cpu().numpy()
+    tot_r = (ref["cost"] * (np.arange(T + 1)[:, None] <= rs[None, :])).sum(0)
+    rel_tot = np.abs(tot_g - tot_r)[same] / np.maximum(np.abs(tot_r[same]), 1e-12)
+    rep = dict(B=B, T=T, done_step_agree=float(same.mean()), survive_to_T=float((rs == T).mean()), curve=curve,
+               cost_abs_err_max=float(cerr.max()), trajectory_cost_rel_err_max=float(rel_tot.max()))
+    _report[f"closed_loop_T200/{name}"] = rep
+    _save_report()
+    print(f"\n[f32 parity (iii)] {name} B={B} T={T}: done_step agreement {same.mean():.5f}, " +
+          ", ".join(f"t={t}: {curve[str(t)]['max_abs']:.2e} ({curve[str(t)]['max_ratio']:.2f}x bound)" for t in curve_t) +
+          f"; trajectory cost rel err max {rel_tot.max():.2e}")
+    assert same.mean() > 0.999
+    assert ratio.max() <= 1.0, f"closed-loop error exceeds 1e-5 |x| + 1e-5 range at some step (max ratio {ratio.max():.2f})"
+    assert rel_tot.max() < 1e-4

@@ -24,13 +24,20 @@ def dev(a, tdt):
 
 
 def check(got, want, tol, scale=None, angle_idx=(), max_bad_frac=0.0):
+    """Per element: |got - want| <= tol * |want| + atol, atol = tol * scale.
+
+    `scale` (default 1) is the magnitude of the largest TERM that enters the quantity for this batch: the f32 forward-error bound of a
+    sum is gamma * sum|terms|, so an element whose own value cancels to ~0 still carries the rounding of its terms, and the
+    float32-rounded inputs alone move a value by eps * |term|.  With tol = 1e-5 (f32) the absolute part is 1e-5 of that term size --
+    about 170 ulps of it; with tol = 1e-12 (f64) it is 4500 ulps of a double."""
     got = got.detach().cpu().numpy().astype(np.float64) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     d = np.abs(wrapped_diff(got, want, angle_idx)) if len(angle_idx) else np.abs(got - want)
-    s = np.maximum(np.abs(want), 1.0 if scale is None else scale)
-    bad = d > tol * s * 8
-    assert bad.mean() <= max_bad_frac, f"max rel err {(d / s).max():.3e} (tol {tol:g}), {bad.mean():.2%} bad, at {np.argwhere(bad)[:4].tolist()}"
+    bound = tol * np.abs(want) + tol * (1.0 if scale is None else scale)
+    bad = d > bound
+    assert bad.mean() <= max_bad_frac, (f"max err / bound {(d / bound).max():.3f} (rtol {tol:g}, atol {tol * (1.0 if scale is None else scale):.3g}), "
+                                        f"{bad.mean():.2%} bad, at {np.argwhere(bad)[:4].tolist()}")
 
 
 def sample_states(name, B, seed=0, spread=1.5):

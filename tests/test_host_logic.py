@@ -271,3 +271,22 @@ def test_graft_entry_build_check_passes():
     """The driver's "does it build" hook: compiles (no-op when current), loads the library, checks symbols and version."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no launcher must START two ranks (round 1 silently ran one): the --dry-run mode goes through
+    the same self-launch path (fresh child processes, RANK / WORLD_SIZE / MASTER_* in their environment), rendezvous over gloo on the
+    CPU, all-reduces the rank ids and prints the launch fields of the JSON line.  Also: a launcher world that contradicts --gpus is an
+    error, not a silent single-rank run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--scaling", "strong", "--steps", "7"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rank_sum"] == 3 and line["steps"] == 7 and line["scaling"] == "strong"
+    assert line["shards"] == [[0, 1 << 19], [1 << 19, 1 << 20]] and line["global_batch"] == 1 << 20
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
