@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"], help="euler = the reference's integrator (parity mode)")
     ap.add_argument("--activation", default="relu", choices=["relu", "tanh"], help="relu = controller/vhjb.py (the BASELINE workload); tanh = the cartpole notebook's network")
     ap.add_argument("--chunk", type=int, default=0, help="steps per persistent launch (0 = all K steps in one launch)")
+    ap.add_argument("--prewarm", type=float, default=0.3, help="seconds of untimed clock pre-warm on scratch state before the W warm-up steps (0 for counter runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (other configs, HBM-bound entry points, optimiser step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
@@ -388,7 +389,7 @@ def main():
     kernel_ms = {}
 
     if fused:
-        walls, launches, live = time_fused(wl, K, W, reps, args.chunk, barrier)
+        walls, launches, live = time_fused(wl, K, W, reps, args.chunk, barrier, prewarm=args.prewarm)
         roofline = mfma_roofline(wl, launches, B)
         kernel_ms["k_vhjb_rollout_mfma_ms_per_launch"] = roofline["avg_launch_ms"]
     else:

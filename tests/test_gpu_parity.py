@@ -308,9 +308,11 @@ def test_rollout_feedback_vs_oracle(name, prec):
             check(got["u"][:P, torch.as_tensor(keep)], want["u"][:P, keep], ttol, np.abs(d.umax).max(), max_bad_frac=mbf)
             check(got["cost"][:P, torch.as_tensor(keep)], want["cost"][:P, keep], ttol, np.abs(want["cost"][:P]).max() + 1, max_bad_frac=mbf)
             if prec == "f64":
-                check(got["traj"], want["traj"], 1e-6, np.abs(x0).max(), angle_idx=ANGLE_IDX[name])
-                check(got["total_cost"], want["total_cost"], 1e-6, np.abs(want["total_cost"]).max())
-                check(got["x_final"], want["x_final"], 1e-6, np.abs(x0).max(), angle_idx=ANGLE_IDX[name])
+                # the whole 60-step horizon: last-bit differences (fma contraction, summation order) grow exponentially on the unstable
+                # plants (the acrobot loop amplifies 1e-16 to ~1e-6 over 60 steps), hence 1e-5 here against 1e-9 for the prefix above
+                check(got["traj"], want["traj"], 1e-5, np.abs(x0).max(), angle_idx=ANGLE_IDX[name])
+                check(got["total_cost"], want["total_cost"], 1e-5, np.abs(want["total_cost"]).max())
+                check(got["x_final"], want["x_final"], 1e-5, np.abs(x0).max(), angle_idx=ANGLE_IDX[name])
 
 
 @pytest.mark.parametrize("name", ["linear", "cartpole", "quad2d", "nearhover"])
