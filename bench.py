@@ -291,6 +291,37 @@ def hbm_entry_points(system="cartpole", B=1 << 20, pool_bytes=640 << 20):
     return rows
 
 
+def param_gradient_kernels(system="nearhover", B=1 << 20):
+    """hjbx_value_loss_grad_f32 (the fused MFMA parameter gradient of the value-learning step) on a full batch: samples/s and the
+    fraction of the f32 MFMA peak, counting ALGORITHMIC flops (2 x MACs of the products in the header of hjbx_train.hip:
+    6 S + 128^2 + 128 x 64 MACs per sample, S = 128 n + 128^2 + 128 x 64)."""
+    from q_learning_with_hjb_amd import _ops
+    wl = make_workload(system, "euler", "relu", B, 17)
+    d, ctl, n = wl["dyn"], wl["ctl"], wl["n"]
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    dones = (torch.rand(B, generator=gen, device="cuda") < 0.1).float()
+    costs = torch.rand(B, generator=gen, device="cuda") * 5
+    desc = wl["vf"].descriptor()
+    out = None
+    for _ in range(3):
+        out = _ops.value_loss_grad(d.system, ctl._task, desc, wl["x0"], costs, dones, out=out)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ops.value_loss_grad(d.system, ctl._task, desc, wl["x0"], costs, dones, out=out)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.median(ts))
+    S = 128 * n + 128 * 128 + 128 * 64
+    flops = 2.0 * (6 * S + 128 * 128 + 128 * 64)
+    ach = flops * B / t / 1e12
+    return dict(name=f"value_loss_grad: parameter gradient of the learning step ({system}, B=2^{int(np.log2(B))})", ms=t * 1e3, samples_per_s=B / t,
+                achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TFLOPS, bound="mfma", flop_per_sample=flops,
+                scratch_bytes_per_sample=2 * 4.0 * 37888 / 32)
+
+
 def optimiser_step(world, dist):
     """params_update (reference controller/vhjb.py:255-288) at the reference's minibatch of 256 samples IN TOTAL (256 / G per rank):
     updates per second including, for G > 1, the flat gradient all-reduce (RCCL)."""
@@ -317,6 +348,7 @@ def optimiser_step(world, dist):
     dt = time.perf_counter() - t0
     return dict(name="params_update (cartpole, minibatch 256 in total)", ranks=world, samples_per_rank=per_rank, updates_per_s=R / dt,
                 samples_per_s=R * per_rank * world / dt, ms_per_update=dt / R * 1e3,
+                gradient=("fused MFMA kernels (hjbx_value_loss_grad_f32)" if ctl.fused_param_grad else "PyTorch autograd"),
                 mode=("hipGraph replay" if ctl.graph_updates else "eager launches" + (" + one flat all-reduce" if world > 1 else "")))
 
 
@@ -432,6 +464,8 @@ def main():
                 del w2
                 torch.cuda.empty_cache()
             sec += hbm_entry_points("cartpole")
+            torch.cuda.empty_cache()
+            sec.append(param_gradient_kernels("nearhover", 1 << 20))
             torch.cuda.empty_cache()
         sec_opt = optimiser_step(world, dist)                  # every rank takes part (all-reduce inside for G > 1)
         if rank == 0:

@@ -277,6 +277,20 @@ int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const h
                           float* resid, int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* workspace,
                           void* stream);
 
+/* The parameter gradient of one value-learning step (vhjb.py:227-253 and the jax.grad calls of :282-284) for a minibatch of B samples
+ * (x (B,n), cost (B,), done (B,) as 0/1 floats), fused on the matrix cores:
+ *   flat = [ d(sum_b hjb_loss_b)/dW1 (n,h1) | /dW2 (h1,h2) | /dW3 (h2,h3) | d(sum_b termination_loss_b)/dW1 | /dW2 | /dW3 |
+ *            sum_b hjb_loss_b, sum_b termination_loss_b, sum_b (1-done_b), sum_b done_b ]                  (2P + 4 floats)
+ * i.e. the gradients of the loss SUMS (the caller divides by the counts, vhjb.py:241, 253, and mixes with the regularisation weight,
+ * :284) -- the buffer a data-parallel step all-reduces once.  hjb_loss is a function of dV/dx, so its gradient is a second-order
+ * reverse sweep; both are evaluated in closed form (no autograd graph).  `mode` = hjbx_residual_mode.  Deterministic: no float atomics,
+ * fixed summation order (the order depends on B and the device's CU count only).  ReLU networks with features [128,128,64] only
+ * (HJBX_EUNSUPPORTED otherwise: the PyTorch autograd path remains).  workspace: hjbx_value_loss_grad_workspace_bytes(B) bytes, 256-byte
+ * aligned, need not be initialised. */
+size_t hjbx_value_loss_grad_workspace_bytes(int64_t B);
+int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
+                             const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

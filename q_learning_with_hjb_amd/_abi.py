@@ -32,7 +32,8 @@ _LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
 # (source, extra flags, object): hjbx_mlp.hip is compiled once per activation (see the top of that file)
 _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=0",), "hjbx_mlp_relu.o"),
-          ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"))
+          ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"),
+          ("hjbx_train.hip", (), "hjbx_train.o"))
 _SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
 _HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 
@@ -194,7 +195,8 @@ def _typed_signatures():
 
 EXPORTED_SYMBOLS = (
     ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_set_option", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
-     "hjbx_reduce_workspace_bytes", "hjbx_rollout_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32"]
+     "hjbx_reduce_workspace_bytes", "hjbx_rollout_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32",
+     "hjbx_value_loss_grad_workspace_bytes", "hjbx_value_loss_grad_f32"]
     + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
 )
 
@@ -230,6 +232,10 @@ def lib() -> C.CDLL:
         L.hjbx_value_grad_f32.argtypes = [_VP, _VP, _VP, _VP, _VP, _I64, _VP]
         L.hjbx_vhjb_rollout_f32.restype = C.c_int
         L.hjbx_vhjb_rollout_f32.argtypes = [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _VP]
+        L.hjbx_value_loss_grad_workspace_bytes.restype = C.c_size_t
+        L.hjbx_value_loss_grad_workspace_bytes.argtypes = [_I64]
+        L.hjbx_value_loss_grad_f32.restype = C.c_int
+        L.hjbx_value_loss_grad_f32.argtypes = [_VP, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")

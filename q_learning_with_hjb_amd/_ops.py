@@ -265,3 +265,26 @@ def vhjb_rollout(sys, task, mlp_desc, x, n_steps, T_max, done_step, t_first=0, i
                                       _p(traj), _p(ulog), _p(cost), _p(done), _p(resid), _p(done_step), _p(x_out), _p(env_order), B,
                                       _p(_rollout_workspace(dev)), _stream()))
     return dict(traj=traj, u=ulog, cost=cost, done=done, residual=resid, x_out=x_out)
+
+
+_tws = {}
+
+
+def value_loss_grad(sys, task, mlp_desc, x, cost, done, mode=_abi.RESIDUAL_NORMALISED, out=None):
+    """Fused parameter gradient of the value-learning step (f32, relu): -> flat (2P + 4,) =
+    [d sum(hjb)/dW1 | dW2 | dW3 | d sum(termination)/dW1 | dW2 | dW3 | sum hjb, sum termination, #interior, #done]."""
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n), torch.float32)
+    _chk(cost, "cost", (B,), torch.float32)
+    _chk(done, "done", (B,), torch.float32)
+    P = sys.n * mlp_desc.h1 + mlp_desc.h1 * mlp_desc.h2 + mlp_desc.h2 * mlp_desc.h3
+    flat = torch.empty((2 * P + 4,), dtype=torch.float32, device=x.device) if out is None else out
+    _chk(flat, "out", (2 * P + 4,), torch.float32)
+    need = lib().hjbx_value_loss_grad_workspace_bytes(B)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _tws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need + 255) // 256 * 256, dtype=torch.uint8, device=x.device)
+        _tws[key] = ws
+    check(lib().hjbx_value_loss_grad_f32(sys.ptr, ref(task), ref(mlp_desc), int(mode), _p(x), _p(cost), _p(done), _p(flat), _p(ws), B, _stream()))
+    return flat

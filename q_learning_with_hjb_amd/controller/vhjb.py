@@ -248,7 +248,7 @@ class VHJBController(Controller):
 
     def __init__(self, dynamics: Dynamics, config, device=None, dtype=torch.float32, process_group=None,
                  residual_mode=_abi.RESIDUAL_NORMALISED, fused_value_grad: Optional[bool] = None,
-                 graph_updates: Optional[bool] = None, activation: str = "relu") -> None:
+                 graph_updates: Optional[bool] = None, activation: str = "relu", fused_param_grad: Optional[bool] = None) -> None:
         super().__init__()
         self.device = torch.device(device) if device is not None else _ops.require_device()
         self.dtype = dtype
@@ -288,6 +288,16 @@ class VHJBController(Controller):
         self.fused_value_grad = (dtype == torch.float32 and fusable) if fused_value_grad is None else bool(fused_value_grad)
         if self.fused_value_grad and not fusable:
             raise NotImplementedError(f"no fused value-gradient kernel for the {activation} activation")
+        # the parameter gradient of the optimiser step: hand-written MFMA kernels (hjbx_value_loss_grad_f32: forward, input gradient,
+        # residuals and the second-order reverse sweep in closed form) for the float32 ReLU network of controller/vhjb.py; anything else
+        # (float64, tanh / sin, HJBX_FUSED_PARAM_GRAD=0) goes through PyTorch autograd
+        can_fuse_pg = (dtype == torch.float32 and activation == "relu" and tuple(config.features) == (128, 128, 64) and self.device.type == "cuda"
+                       and not config.using_batch_norm)
+        if fused_param_grad is None:
+            fused_param_grad = can_fuse_pg and os.environ.get("HJBX_FUSED_PARAM_GRAD", "1") != "0"
+        if fused_param_grad and not can_fuse_pg:
+            raise NotImplementedError("the fused parameter-gradient kernels exist for the float32 ReLU network with features [128, 128, 64] only")
+        self.fused_param_grad = bool(fused_param_grad)
         # fused rollouts of big batches re-pack live environments every `compaction_interval` steps (0 = never)
         self.compaction_interval, self.compaction_min_batch = 16, 8192
         self.train_mode = False
@@ -514,28 +524,36 @@ class VHJBController(Controller):
 
     def _update_core(self, xs, dones, costs, regularization):
         """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph."""
-        params = list(self.value_function_approximator.parameters())
-        # differentiate w.r.t. fresh leaves that alias the parameters: their grad accumulators are created on the stream this
-        # step runs on, so a hipGraph capture cannot be joined to the stream of an older, still-alive autograd graph of the
-        # same parameters (that unjoined cross-stream wait crashes hipStreamEndCapture)
-        leaves = [p.detach().requires_grad_(True) for p in params]
-        V, g = self.value_function_approximator.value_and_grad(xs, weights=leaves)
-        h_sum, h_sums = _HJBResidualSum.apply(g, xs, dones, self.dynamics.system, self._task, self.residual_mode)
-        t_sum, _ = _TerminationResidualSum.apply(V, costs, dones, self.epsilon)
-        params, model_params = leaves, params
-        if self._distributed():
-            g_h = torch.autograd.grad(h_sum, params, retain_graph=True, allow_unused=True)
-            g_t = torch.autograd.grad(t_sum, params, allow_unused=True)
-            grads, hjb_loss, termination_loss = allreduce_and_mix(g_h, g_t, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]), params,
-                                                                  regularization, self.epsilon, self.process_group)
+        model_params = list(self.value_function_approximator.parameters())
+        if self.fused_param_grad:
+            # one C-ABI call: [d sum(hjb)/dW | d sum(termination)/dW | sum hjb, sum termination, #interior, #done] -- exactly the buffer
+            # the data-parallel step all-reduces once; then the division by the (global) counts and the mix (vhjb.py:241, 253, 284)
+            flat = _ops.value_loss_grad(self.dynamics.system, self._task, self.value_function_approximator.descriptor(), xs, costs, dones,
+                                        self.residual_mode)
+            if self._distributed():
+                torch.distributed.all_reduce(flat, group=self.process_group)
+            grads, hjb_loss, termination_loss = mix_flat(flat, model_params, regularization, self.epsilon)
         else:
-            # one process: the normalisers are known before the backward pass, so ONE reverse sweep of the mixed loss gives
-            # grad(hjb) + regularization * grad(termination) (vhjb.py:282-284) in half the kernels
-            hjb_t = h_sum / (h_sums[1] + self.epsilon)
-            term_t = t_sum / (h_sums[2] + self.epsilon)
-            grads = torch.autograd.grad(hjb_t + regularization * term_t, params, allow_unused=True)
-            grads = [torch.zeros_like(p) if gr is None else gr for p, gr in zip(params, grads)]
-            hjb_loss, termination_loss = hjb_t.detach(), term_t.detach()
+            # differentiate w.r.t. fresh leaves that alias the parameters: their grad accumulators are created on the stream this
+            # step runs on, so a hipGraph capture cannot be joined to the stream of an older, still-alive autograd graph of the
+            # same parameters (that unjoined cross-stream wait crashes hipStreamEndCapture)
+            params = [p.detach().requires_grad_(True) for p in model_params]
+            V, g = self.value_function_approximator.value_and_grad(xs, weights=params)
+            h_sum, h_sums = _HJBResidualSum.apply(g, xs, dones, self.dynamics.system, self._task, self.residual_mode)
+            t_sum, _ = _TerminationResidualSum.apply(V, costs, dones, self.epsilon)
+            if self._distributed():
+                g_h = torch.autograd.grad(h_sum, params, retain_graph=True, allow_unused=True)
+                g_t = torch.autograd.grad(t_sum, params, allow_unused=True)
+                grads, hjb_loss, termination_loss = allreduce_and_mix(g_h, g_t, (h_sum.detach(), t_sum.detach(), h_sums[1], h_sums[2]), params,
+                                                                      regularization, self.epsilon, self.process_group)
+            else:
+                # one process: the normalisers are known before the backward pass, so ONE reverse sweep of the mixed loss gives
+                # grad(hjb) + regularization * grad(termination) (vhjb.py:282-284) in half the kernels
+                hjb_t = h_sum / (h_sums[1] + self.epsilon)
+                term_t = t_sum / (h_sums[2] + self.epsilon)
+                grads = torch.autograd.grad(hjb_t + regularization * term_t, params, allow_unused=True)
+                grads = [torch.zeros_like(p) if gr is None else gr for p, gr in zip(params, grads)]
+                hjb_loss, termination_loss = hjb_t.detach(), term_t.detach()
         for p, gr in zip(model_params, grads):
             p.grad = gr
         self.optimizer.step()
@@ -673,6 +691,20 @@ def allreduce_and_mix(g_h, g_t, scalars, params, regularization, epsilon, proces
     termination_loss = ts / (n_done + epsilon)
     grads = [a / (n_int + epsilon) + regularization * (b / (n_done + epsilon)) for a, b in zip(g_h, g_t)]
     return grads, hjb_loss, termination_loss
+
+
+def mix_flat(flat: torch.Tensor, params, regularization, epsilon):
+    """[g_h | g_t | sum hjb, sum termination, #interior, #done] (already summed over the ranks) -> (mixed grads as views of ONE buffer,
+    hjb_loss, termination_loss): grad = g_h / (#interior + eps) + regularization * g_t / (#done + eps), vhjb.py:241, 253, 284."""
+    P = sum(p.numel() for p in params)
+    hs, ts, n_int, n_done = flat[2 * P], flat[2 * P + 1], flat[2 * P + 2], flat[2 * P + 3]
+    ih, it = 1.0 / (n_int + epsilon), 1.0 / (n_done + epsilon)
+    mixed = flat[:P] * ih + flat[P:2 * P] * (regularization * it)
+    grads, off = [], 0
+    for p in params:
+        grads.append(mixed[off:off + p.numel()].view_as(p))
+        off += p.numel()
+    return grads, hs * ih, ts * it
 
 
 def pack_flat(g_h, g_t, params, scalars) -> torch.Tensor:

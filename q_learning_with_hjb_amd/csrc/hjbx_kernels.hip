@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "hjbx_internal.hpp"
 #include "hjbx_systems.hpp"
@@ -83,6 +84,13 @@ static constexpr int kBlock = 256;        // 4 waves per workgroup
 static constexpr int kReduceBlocks = 1024;  // grid cap of the reducing kernels (4 per CU); 4096 measured no better
 
 static inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
+static inline dim3 grid_rows(int64_t B, int R) { return dim3((unsigned)((B + (int64_t)kBlock * R - 1) / ((int64_t)kBlock * R))); }
+// rows per thread of the streaming kernels: enough loads in flight to cover the HBM latency once the batch fills the chip; small
+// batches keep one row per thread (more workgroups); float64 keeps one row (its row state alone is 2x the registers)
+template <typename T> static inline int rows_per_thread(int64_t B, int n) {
+    if (sizeof(T) != 4) return 1;
+    return B >= (1 << 19) ? (n <= 4 ? 4 : 2) : (B >= (1 << 17) ? 2 : 1);   // wide rows: 4 of them would cost a resident wave per SIMD
+}
 
 // ----------------------------------------------------------------------------------------------
 // pointwise kernels
@@ -130,17 +138,33 @@ __global__ __launch_bounds__(kBlock) void k_xdot(S sys, const T* __restrict__ x,
     RowIO<T, S::N>::store(xd, i, d);
 }
 
-template <int INTEG, typename S, typename T>
+// R rows per thread, all loads issued before the first use: a 36 MB kernel at 6 TB/s lasts 6 us, and with one row per thread the
+// 16 workgroups a CU receives run as two resident rounds of (HBM latency + compute + store) -- latency bound, 4.1 TB/s measured
+// with buffers that miss the Infinity Cache (profiles/r02_kernel_bench.json).  Row r of a thread is block_base + r kBlock + tid,
+// so every load instruction of a wave stays one coalesced segment.
+template <int INTEG, int R, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_simulate(S sys, Limits<T, S::M> lim, const T* x, const T* __restrict__ u,
                                                      T* xn, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], us[S::M], uc[S::M], o[S::N];
-    RowIO<T, S::N>::load(x, i, xs);
-    RowIO<T, S::M>::load(u, i, us);
-    clip_u<T, S::M>(lim, us, uc);
-    integrate<INTEG>(sys, lim.dt, xs, uc, o);
-    RowIO<T, S::N>::store(xn, i, o);
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
+    T xs[R][S::N], us[R][S::M];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = base + r * kBlock;
+        if (i < B) {
+            RowIO<T, S::N>::load(x, i, xs[r]);
+            RowIO<T, S::M>::load(u, i, us[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = base + r * kBlock;
+        if (i < B) {
+            T uc[S::M], o[S::N];
+            clip_u<T, S::M>(lim, us[r], uc);
+            integrate<INTEG>(sys, lim.dt, xs[r], uc, o);
+            RowIO<T, S::N>::store(xn, i, o);
+        }
+    }
 }
 
 template <typename S, typename T> struct X0P { T mean[S::N], std[S::N]; };
@@ -286,78 +310,35 @@ __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S
                                                          const T* __restrict__ x, const T* __restrict__ g,
                                                          const T* __restrict__ done, T* __restrict__ loss_i,
                                                          T* __restrict__ dl_dg, unsigned char* ws, T* __restrict__ sums, int64_t B) {
-    constexpr int N = S::N, M = S::M;
+    constexpr int N = S::N;
+    constexpr int R = sizeof(T) == 4 ? (N <= 4 ? 4 : 2) : 1;   // rows in flight per thread (see k_simulate); the grid is capped at kReduceBlocks workgroups
     double acc_l = 0, acc_nb = 0, acc_nd = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
-        T xs[N], gs[N], f1[N], f2[N * M], ur[M], u[M], e[N], xd[N];
-        RowIO<T, N>::load(x, i, xs);
-        RowIO<T, N>::load(g, i, gs);
-        const T dn = done[i];
-        sys.affine(xs, f1, f2);
-        control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
-        T vdot = T(0);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < B; i0 += R * stride) {
+        T xs[R][N], gs[R][N], dnv[R];
 #pragma unroll
-        for (int r = 0; r < N; ++r) {
-            T a = T(0);
-#pragma unroll
-            for (int j = 0; j < M; ++j) a += f2[r * M + j] * u[j];
-            xd[r] = f1[r] + a;
-            vdot += gs[r] * xd[r];
-        }
-        error_coords(sys, tk.xf, xs, e);
-        const T l = running_cost_e<S, T>(tk, e, u);
-        const T den = l + tk.eps;
-        // float: one reciprocal per environment (the gradient below would otherwise need 2 divisions per state dimension);
-        // double keeps the reference's divisions in place (vhjb.py:233), like the dynamics structs do (hjbx_systems.hpp)
-        const T iden = T(1) / den;
-        T r;
-        if constexpr (MODE != 0) r = vdot + l;
-        else if constexpr (sizeof(T) == 4) r = vdot * iden + T(1);
-        else r = vdot / den + T(1);
-        const T w = T(1) - dn;
-        const T li = abs_t(r) * w;
-        if (loss_i) loss_i[i] = li;
-        if (dl_dg) {
-            // du/dg = -1/2 D Rinv f2' ; dV./dg = xdot + (du/dg)' f2' g ; dl/dg = (du/dg)' (R+R')(u-uf)
-            T f2tg[M], rdu[M];
-            bool open[M];
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                T a = T(0);
-#pragma unroll
-                for (int k = 0; k < N; ++k) a += f2[k * M + j] * gs[k];
-                f2tg[j] = a;
-                T b = T(0);
-#pragma unroll
-                for (int k = 0; k < M; ++k) b += (tk.R[j * M + k] + tk.R[k * M + j]) * (u[k] - tk.uf[k]);
-                rdu[j] = b;
-                open[j] = tk.law == 0 && (ur[j] > lim.umin[j]) && (ur[j] < lim.umax[j]);
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = i0 + r * stride;
+            if (i < B) {
+                RowIO<T, N>::load(x, i, xs[r]);
+                RowIO<T, N>::load(g, i, gs[r]);
+                dnv[r] = done[i];
             }
-            const T sg = (r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0));
-            T out[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                T dv = xd[k], dl = T(0);
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    T a = T(0);
-#pragma unroll
-                    for (int q = 0; q < M; ++q) a += tk.Rinv[j * M + q] * f2[k * M + q];
-                    const T dudg = open[j] ? -a / T(2) : T(0);
-                    dv += dudg * f2tg[j];
-                    dl += dudg * rdu[j];
-                }
-                T dr;
-                if constexpr (MODE != 0) dr = dv + dl;
-                else if constexpr (sizeof(T) == 4) dr = dv * iden - (vdot * iden * iden) * dl;
-                else dr = dv / den - vdot * dl / (den * den);
-                out[k] = sg * w * dr;
-            }
-            RowIO<T, N>::store(dl_dg, i, out);
         }
-        acc_l += (double)li;
-        acc_nb += (double)w;
-        acc_nd += (double)dn;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = i0 + r * stride;
+            if (i < B) {
+                T out[N], li;
+                const T dn = dnv[r];
+                hjb_residual_env<MODE>(sys, tk, lim, xs[r], gs[r], dn, dl_dg != nullptr, li, out);
+                if (loss_i) loss_i[i] = li;
+                if (dl_dg) RowIO<T, N>::store(dl_dg, i, out);
+                acc_l += (double)li;
+                acc_nb += (double)(T(1) - dn);
+                acc_nd += (double)dn;
+            }
+        }
     }
     if (ws) block_sum3<T>(acc_l, acc_nb, acc_nd, ws, sums);
 }
@@ -370,11 +351,10 @@ __global__ __launch_bounds__(kBlock) void k_termination_residual(T eps, const T*
     double acc_l = 0, acc_nb = 0, acc_nd = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
         const T dn = done[i];
-        const T den = cost[i] + eps;
-        const T r = V[i] / den - T(1);
-        const T li = abs_t(r) * dn;
+        T li, dv;
+        termination_residual_env<T>(eps, V[i], cost[i], dn, li, dv);
         if (loss_i) loss_i[i] = li;
-        if (dl_dV) dl_dV[i] = ((r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0))) * dn / den;
+        if (dl_dV) dl_dV[i] = dv;
         acc_l += (double)li;
         acc_nb += 1.0 - (double)dn;
         acc_nd += (double)dn;
@@ -385,27 +365,40 @@ __global__ __launch_bounds__(kBlock) void k_termination_residual(T eps, const T*
 // ----------------------------------------------------------------------------------------------
 // closed loop: one VHJB step given gradV, and whole rollouts under closed-form controllers
 // ----------------------------------------------------------------------------------------------
-template <int INTEG, typename S, typename T>
+template <int INTEG, int R, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim, int t, int T_max,
                                                       const T* x, const T* __restrict__ g, T* xn, T* __restrict__ u_out,
                                                       T* __restrict__ cost_t, T* __restrict__ done_t,
                                                       int32_t* __restrict__ done_step, T* __restrict__ resid_t, int64_t B) {
     constexpr int N = S::N, M = S::M;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[N], gs[N], xo[N], u[M];
-    RowIO<T, N>::load(x, i, xs);
-    RowIO<T, N>::load(g, i, gs);
-    int32_t ds = done_step[i];
-    const int32_t ds_in = ds;
-    T c, d, res;
-    vhjb_step_env<INTEG>(sys, tk, lim, t, T_max, resid_t != nullptr, xs, gs, ds, xo, u, c, d, res);
-    if (ds != ds_in) done_step[i] = ds;
-    RowIO<T, N>::store(xn, i, xo);
-    if (u_out) RowIO<T, M>::store(u_out, i, u);
-    cost_t[i] = c;
-    done_t[i] = d;
-    if (resid_t) resid_t[i] = res;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
+    T xs[R][N], gs[R][N];
+    int32_t dsv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {   // (see k_simulate: all loads first)
+        const int64_t i = base + r * kBlock;
+        if (i < B) {
+            RowIO<T, N>::load(x, i, xs[r]);
+            RowIO<T, N>::load(g, i, gs[r]);
+            dsv[r] = done_step[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = base + r * kBlock;
+        if (i < B) {
+            T xo[N], u[M];
+            int32_t ds = dsv[r];
+            T c, d, res;
+            vhjb_step_env<INTEG>(sys, tk, lim, t, T_max, resid_t != nullptr, xs[r], gs[r], ds, xo, u, c, d, res);
+            if (ds != dsv[r]) done_step[i] = ds;
+            RowIO<T, N>::store(xn, i, xo);
+            if (u_out) RowIO<T, M>::store(u_out, i, u);
+            cost_t[i] = c;
+            done_t[i] = d;
+            if (resid_t) resid_t[i] = res;
+        }
+    }
 }
 
 template <int INTEG, int CK, typename S, typename T>
@@ -519,12 +512,19 @@ static int simulate_impl(const hjbx_system* sys, int integ, const T* x, const T*
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto lim = make_limits<T, SS::M>(sys);
-            if (integ == HJBX_EULER)
-                hipLaunchKernelGGL((k_simulate<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
-            else if (integ == HJBX_RK4)
-                hipLaunchKernelGGL((k_simulate<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
-            else if constexpr (is_linear<SS>::value)
-                hipLaunchKernelGGL((k_simulate<2, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
+            auto go = [&](auto integc, auto rc) {
+                constexpr int I = decltype(integc)::value, R = decltype(rc)::value;
+                hipLaunchKernelGGL((k_simulate<I, R, SS, T>), grid_rows(B, R), dim3(kBlock), 0, (hipStream_t)st, S, lim, x, u, xn, B);
+            };
+            auto with_r = [&](auto integc) {
+                const int R = rows_per_thread<T>(B, SS::N);
+                if (R == 4) go(integc, std::integral_constant<int, 4>{});
+                else if (R == 2) go(integc, std::integral_constant<int, 2>{});
+                else go(integc, std::integral_constant<int, 1>{});
+            };
+            if (integ == HJBX_EULER) with_r(std::integral_constant<int, 0>{});
+            else if (integ == HJBX_RK4) with_r(std::integral_constant<int, 1>{});
+            else if constexpr (is_linear<SS>::value) with_r(std::integral_constant<int, 2>{});
         })) return unsupported(sys);
     return check_launch("hjbx_simulate");
 }
@@ -645,15 +645,20 @@ static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int int
             using SS = decltype(S);
             auto tk = make_task<T, SS::N, SS::M>(task);
             auto lim = make_limits<T, SS::M>(sys);
-            if (integ == HJBX_EULER)
-                hipLaunchKernelGGL((k_vhjb_step<0, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
+            auto go = [&](auto integc, auto rc) {
+                constexpr int I = decltype(integc)::value, R = decltype(rc)::value;
+                hipLaunchKernelGGL((k_vhjb_step<I, R, SS, T>), grid_rows(B, R), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
                                    g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
-            else if (integ == HJBX_RK4)
-                hipLaunchKernelGGL((k_vhjb_step<1, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
-                                   g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
-            else if constexpr (is_linear<SS>::value)
-                hipLaunchKernelGGL((k_vhjb_step<2, SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, t, T_max, x,
-                                   g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
+            };
+            auto with_r = [&](auto integc) {
+                const int R = rows_per_thread<T>(B, SS::N);
+                if (R == 4) go(integc, std::integral_constant<int, 4>{});
+                else if (R == 2) go(integc, std::integral_constant<int, 2>{});
+                else go(integc, std::integral_constant<int, 1>{});
+            };
+            if (integ == HJBX_EULER) with_r(std::integral_constant<int, 0>{});
+            else if (integ == HJBX_RK4) with_r(std::integral_constant<int, 1>{});
+            else if constexpr (is_linear<SS>::value) with_r(std::integral_constant<int, 2>{});
         })) return unsupported(sys);
     return check_launch("hjbx_vhjb_step");
 }

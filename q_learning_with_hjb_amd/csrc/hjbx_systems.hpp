@@ -426,6 +426,83 @@ HJBX_DEV void vhjb_step_env(const S& sys, const TaskP<T, S::N, S::M>& tk, const 
     }
 }
 
+// hjb_loss body for ONE sample (reference vhjb.py:227-241) with the analytic derivative of the loss w.r.t. gradV: shared
+// by hjbx_hjb_residual and the fused value-loss-gradient kernel (hjbx_train.hip), so the two produce identical bits.
+//   u_raw = -Rinv f2' g / 2 + uf, u = clip(u_raw); xdot = f1 + f2 u; l = e'Qe + (u-uf)'R(u-uf)
+//   r = g.xdot / (l + eps) + 1 (MODE 0, vhjb.py:233) | g.xdot + l (MODE 1: cartpole notebook cell 11); loss = |r| (1 - done)
+//   du/dg = -1/2 D Rinv f2' (D = 1 where the clip is inactive); dV./dg = xdot + (du/dg)' f2' g; dl/dg = (du/dg)' (R+R')(u-uf)
+template <int MODE, typename S, typename T>
+HJBX_DEV void hjb_residual_env(const S& sys, const TaskP<T, S::N, S::M>& tk, const Limits<T, S::M>& lim, const T* xs, const T* gs, T dn,
+                               bool want_grad, T& li, T* out) {
+    constexpr int N = S::N, M = S::M;
+    T f1[N], f2[N * M], ur[M], u[M], e[N], xd[N];
+    sys.affine(xs, f1, f2);
+    control_from_grad<S, T>(tk, lim, f2, gs, ur, u);
+    T vdot = T(0);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        T a = T(0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) a += f2[r * M + j] * u[j];
+        xd[r] = f1[r] + a;
+        vdot += gs[r] * xd[r];
+    }
+    error_coords(sys, tk.xf, xs, e);
+    const T l = running_cost_e<S, T>(tk, e, u);
+    const T den = l + tk.eps;
+    // float: one reciprocal per sample (the gradient below would otherwise need 2 divisions per state dimension);
+    // double keeps the reference's divisions in place (vhjb.py:233), like the dynamics structs above do
+    const T iden = T(1) / den;
+    T r;
+    if constexpr (MODE != 0) r = vdot + l;
+    else if constexpr (sizeof(T) == 4) r = vdot * iden + T(1);
+    else r = vdot / den + T(1);
+    const T w = T(1) - dn;
+    li = abs_t(r) * w;
+    if (!want_grad) return;
+    T f2tg[M], rdu[M];
+    bool open[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        T a = T(0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) a += f2[k * M + j] * gs[k];
+        f2tg[j] = a;
+        T b = T(0);
+#pragma unroll
+        for (int k = 0; k < M; ++k) b += (tk.R[j * M + k] + tk.R[k * M + j]) * (u[k] - tk.uf[k]);
+        rdu[j] = b;
+        open[j] = tk.law == 0 && (ur[j] > lim.umin[j]) && (ur[j] < lim.umax[j]);
+    }
+    const T sg = (r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0));
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        T dv = xd[k], dl = T(0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            T a = T(0);
+#pragma unroll
+            for (int q = 0; q < M; ++q) a += tk.Rinv[j * M + q] * f2[k * M + q];
+            const T dudg = open[j] ? -a / T(2) : T(0);
+            dv += dudg * f2tg[j];
+            dl += dudg * rdu[j];
+        }
+        T dr;
+        if constexpr (MODE != 0) dr = dv + dl;
+        else if constexpr (sizeof(T) == 4) dr = dv * iden - (vdot * iden * iden) * dl;
+        else dr = dv / den - vdot * dl / (den * den);
+        out[k] = sg * w * dr;
+    }
+}
+
+// termination_loss body for ONE sample (vhjb.py:243-253): loss = |V / (cost + eps) - 1| done; dloss/dV = sign(.) done / (cost + eps)
+template <typename T> HJBX_DEV void termination_residual_env(T eps, T V, T cost, T dn, T& li, T& dl_dV) {
+    const T den = cost + eps;
+    const T r = V / den - T(1);
+    li = abs_t(r) * dn;
+    dl_dV = ((r > T(0)) ? T(1) : ((r < T(0)) ? T(-1) : T(0))) * dn / den;
+}
+
 // ---- closed-form controllers -----------------------------------------------------------
 // CK = 0 linear feedback (lqr.py:25-26; quadrotors_model_based_controller.py:36-38, 73-75)
 // CK = 1 cartpole energy shaping (cartpole_energy_shaping.py:65-110), CK = 2 acrobot (acrobot_energy_shaping.py:74-121)

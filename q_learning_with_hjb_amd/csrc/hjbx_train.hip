@@ -1,0 +1,533 @@
+// hjbx_train.hip -- the parameter gradient of the value-learning step (reference controller/vhjb.py:227-253, 282-284) on the f32
+// matrix cores: d(sum_b hjb_loss_b)/dW and d(sum_b termination_loss_b)/dW for W1, W2, W3 of the 3-layer value network, plus the loss
+// sums and the two counts, for a batch of B samples (x, cost, done).  hjb_loss depends on the weights through dV/dx, so its
+// parameter gradient is a second-order reverse sweep ("double back-prop": jax.grad of a function of jax.grad in the reference).
+//
+// Per sample (notation of hjbx_mlp.hip; s1, s2 = act'(a1), act'(a2); ReLU, so act'' = 0):
+//   forward            h1 = act(W1'z)   h2 = act(W2'h1)   y = W3'h2   V = |y|^2 + eps_s |e|^2
+//   input gradient     dy = 2y   d2 = (W3 dy).s2   d1 = (W2 d2).s1   g = (W1 d1)/std + 2 eps_s e
+//   losses             l_h(g; x) with q = dl_h/dg (hjb_residual_env)      l_t(V) with r = dl_t/dV (termination_residual_env)
+//   reverse sweep (q)  gzb = q/std   dh1b = (W1'gzb).s1   dh2b = (W2'dh1b).s2   yb = 2 W3'dh2b   a2b = (W3 yb).s2   a1b = (W2 a2b).s1
+//   hjb gradient       dW1 = gzb (x) d1 + z (x) a1b      dW2 = dh1b (x) d2 + h1 (x) a2b      dW3 = dh2b (x) dy + h2 (x) yb
+//   termination grad.  dW1 = z (x) (r d1)                dW2 = h1 (x) (r d2)                 dW3 = h2 (x) (r dy)
+// ((x) = outer product summed over the batch; the termination gradient is ordinary back-prop of r V, whose intermediates are r times
+// the input-gradient intermediates.)
+//
+// Two kernels, because the two halves want opposite register layouts:
+//  * k_train_chains -- every matrix-vector product above as an MFMA chain, one 32-sample tile per wave, exactly like the inference
+//    kernel (features x samples: a layer's accumulators are the next chain's B operands, weights in LDS).  It writes the twelve
+//    operand arrays of the outer products to a scratch buffer, 4.7 KB per sample.
+//  * k_train_outer -- the outer products are GEMMs whose contraction index is the SAMPLE, so both operands need the feature on the
+//    lane.  One workgroup per CU streams tiles of the scratch through LDS (double buffered half tiles) and its 8 waves own the 56
+//    32x32 output blocks (hjb + termination sets of W1, W2, W3) as MFMA accumulators for the whole launch; per-workgroup partial
+//    sums go to the workspace and k_train_reduce adds them in workgroup order (deterministic, no float atomics) into the flat
+//    buffer [dW1_h | dW2_h | dW3_h | dW1_t | dW2_t | dW3_t | sum l_h, sum l_t, #interior, #done] -- the layout of the single
+//    all-reduce of the data-parallel step (controller/vhjb.py: pack_flat).
+// Scratch traffic (written once, read once) is 9.5 KB per sample against 0.37 Mflop: both kernels stay MFMA bound.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "hjbx_internal.hpp"
+#include "hjbx_systems.hpp"
+#include "hjbx_host.hpp"
+#include "hjbx_mlp_core.hpp"
+
+using namespace hjbx;
+
+static constexpr int kTrWaves = 8;
+
+// ---- scratch layout of one 32-sample tile (floats) --------------------------------------------------------------------------
+// A 128-feature array is 32 groups of [32 samples][4 features]: group (fb, q, hh) holds features 32 fb + 8 q + 4 hh + 0..3, i.e.
+// exactly the four accumulator registers 4q..4q+3 of block fb in lane half hh -- one coalesced float4 store per lane and group.
+enum { A_H1 = 0, A_DH1B, A_D2, A_A2B, A_H2, A_DH2B, A_D1, A_A1B, A_DY, A_YB, A_COUNT };
+static constexpr int kGroupFloats = 32 * 4;
+static constexpr int kGroups128 = 32, kGroups64 = 16;
+static constexpr int kTileGroups = 8 * kGroups128 + 2 * kGroups64;      // 288
+static constexpr int kSmallW = 32;                                      // per sample: z (n), gzb (n), r, zero padding
+static constexpr int kSmallOff = kTileGroups * kGroupFloats;            // 36864
+static constexpr int kTileFloats = kSmallOff + 32 * kSmallW;            // 37888 floats = 151,552 bytes per tile
+__host__ __device__ constexpr int group0(int a) { return a < 8 ? a * kGroups128 : 8 * kGroups128 + (a - 8) * kGroups64; }
+
+template <int NB> __device__ __forceinline__ void store_tile_array(float* __restrict__ tile, int a, const f32x16 (&v)[NB], int e, int hh) {
+    float* base = tile + group0(a) * kGroupFloats;
+#pragma unroll
+    for (int fb = 0; fb < NB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(base + (((fb * 4 + q) * 2 + hh) * 32 + e) * 4) =
+                make_float4(v[fb][4 * q], v[fb][4 * q + 1], v[fb][4 * q + 2], v[fb][4 * q + 3]);
+}
+
+// ReLU derivative masks: the 64 features a lane half holds per 128-feature array -> 2 words (bit 16 (fb & 1) + r of word fb >> 1),
+// taken from the activations (h >= +0, so h > 0 <=> its bits are non-zero).  Two registers per layer instead of keeping the 64
+// activation registers alive through the whole reverse sweep (the first version of this kernel did, and spilled 120 registers).
+__device__ __forceinline__ void relu_mask_build(const f32x16 (&hv)[4], uint32_t (&m)[2]) {
+    m[0] = m[1] = 0u;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t nz = __builtin_bit_cast(uint32_t, hv[fb][r]);
+            m[fb >> 1] |= (nz < 1u ? nz : 1u) << (16 * (fb & 1) + r);   // v_min_u32 + v_lshl_or_b32, no VCC
+        }
+}
+__device__ __forceinline__ void relu_mask_apply(f32x16 (&v)[4], const uint32_t (&m)[2]) {
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[fb][r] *= (float)((m[fb >> 1] >> (16 * (fb & 1) + r)) & 1u);   // v_bfe_u32 + v_cvt + v_mul
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- kernel 1: all matrix-vector chains of one tile per wave --------------------------------------------------------------
+template <int MODE, typename S, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
+                                                                      Limits<float, S::M> lim_k, const float* __restrict__ W1g,
+                                                                      const float* __restrict__ W2g, const float* __restrict__ W3g,
+                                                                      const float* __restrict__ x, const float* __restrict__ cost,
+                                                                      const float* __restrict__ done, float eps_term, float* __restrict__ scratch,
+                                                                      double* __restrict__ sums_rec, int64_t B, int64_t ntiles) {
+    constexpr int N = S::N, M = S::M, ACT = HJBX_ACT_RELU;
+    constexpr int NP = MlpLds<N>::NP;
+    static_assert(N % 2 == 0 && 2 * N + 1 <= kSmallW, "state dimension");
+    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    __shared__ __attribute__((aligned(16))) unsigned char sys_raw[sizeof(S)];
+    S& sys_s = *reinterpret_cast<S*>(sys_raw);
+    __shared__ MlpP<N> p_s;
+    __shared__ TaskP<float, N, M> tk_s;
+    __shared__ Limits<float, M> lim_s;
+    __shared__ double red[4][WAVES];
+    const int tid = threadIdx.x;
+    if (tid == 0) { sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k; }
+    mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    __syncthreads();
+    const S& sys = sys_s;
+    const MlpP<N>& p = p_s;
+    const TaskP<float, N, M>& tk = tk_s;
+    const Limits<float, M>& lim = lim_s;
+    const int lane = tid & 63, wave = tid >> 6;
+    const MlpCtx c = mlp_ctx<N>(L, lane);
+    const int i = c.i, h = c.h;
+    double acc_h = 0, acc_t = 0, acc_ni = 0, acc_nd = 0;
+    // tiles are dealt wave-major over the workgroups (tile = (wave + WAVES k) gridDim + block): a small batch spreads one wave per CU
+    for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)WAVES * gridDim.x) {
+        asm volatile("" ::: "memory");   // the weights are loop invariant: keep their LDS reads inside the loop (see hjbx_mlp.hip)
+        const int64_t env = tile * 32 + i;
+        const bool valid = env < B;
+        float xs[N];
+        if (valid) load_row<N>(x, env, xs);
+        else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) xs[k] = p.xf[k];
+        }
+        const float dn = valid ? done[env] : 0.f;
+        const float cst = valid ? cost[env] : 1.f;
+        float* tb = scratch + tile * (int64_t)kTileFloats;
+        float e[N], z[N], ee = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) e[k] = xs[k] - p.xf[k];
+        sys.wrap(e);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            ee += e[k] * e[k];
+            z[k] = (e[k] - p.mean[k]) * p.istd[k];
+        }
+        float ring4[3][4], ring2[3][2];
+        auto zB = [&](int st, int) { return h ? z[2 * st + 1] : z[2 * st]; };
+
+        // ---- forward -------------------------------------------------------------------------------------------------
+        uint32_t m1[2], m2[2];
+        f32x16 a1[1][4];
+        zero_acc(a1);
+        mfma_chain<OffW1F, N / 2, 4, 2, 1>(a1, ring4, c.w1f, zB);
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[0][fb][r] = act1<ACT>(a1[0][fb][r]);
+        relu_mask_build(a1[0], m1);
+        store_tile_array<4>(tb, A_H1, a1[0], i, h);
+        f32x16 a2[1][4];
+        zero_acc(a2);
+        mfma_chain<OffW2F, 64, 4, 2, 1>(a2, ring4, c.w2f, [&](int st, int) { return a1[0][st >> 4][st & 15]; });
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[0][fb][r] = act1<ACT>(a2[0][fb][r]);
+        relu_mask_build(a2[0], m2);
+        store_tile_array<4>(tb, A_H2, a2[0], i, h);
+        f32x16 y[1][2];
+        zero_acc(y);
+        mfma_chain<OffW3F, 64, 2, 2, 1>(y, ring2, c.w3f, [&](int st, int) { return a2[0][st >> 4][st & 15]; });
+        float vpart = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                vpart += y[0][ob][r] * y[0][ob][r];
+                y[0][ob][r] += y[0][ob][r];   // dy = 2y
+            }
+        const float V = vpart + __shfl_xor(vpart, 32, 64) + p.eps_s * ee;
+        store_tile_array<2>(tb, A_DY, y[0], i, h);
+
+        // ---- input gradient ------------------------------------------------------------------------------------------
+        f32x16 d2[1][4];
+        zero_acc(d2);
+        mfma_chain<OffW3B, 32, 4, 2, 1>(d2, ring4, c.w3b, [&](int st, int) { return y[0][st >> 4][st & 15]; });
+        relu_mask_apply(d2[0], m2);
+        store_tile_array<4>(tb, A_D2, d2[0], i, h);
+        f32x16 d1[1][4];
+        zero_acc(d1);
+        mfma_chain<OffW2B, 64, 4, 2, 1>(d1, ring4, c.w2b, [&](int st, int) { return d2[0][st >> 4][st & 15]; });
+        relu_mask_apply(d1[0], m1);
+        store_tile_array<4>(tb, A_D1, d1[0], i, h);
+        float g[N];
+        {
+            f32x2 part[NP / 2];
+#pragma unroll
+            for (int k = 0; k < NP / 2; ++k) part[k] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float dv = d1[0][kb][s];
+                    const f32x2 dv2{dv, dv};
+#pragma unroll
+                    for (int q = 0; q < NP / 4; ++q) {
+                        const float4 w = c.w1t[(32 * kb + perm(s)) * (NP / 4) + q];
+                        part[2 * q + 0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dv2, part[2 * q + 0]);
+                        part[2 * q + 1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dv2, part[2 * q + 1]);
+                    }
+                }
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float pk = part[k >> 1][k & 1];
+                g[k] = (pk + __shfl_xor(pk, 32, 64)) * p.istd[k] + 2.f * p.eps_s * e[k];
+            }
+        }
+
+        // ---- the two losses and their derivatives w.r.t. dV/dx and V (the same device functions as hjbx_hjb_residual /
+        //      hjbx_termination_residual) ---------------------------------------------------------------------------------
+        float li, q[N], lt, r;
+        hjb_residual_env<MODE>(sys, tk, lim, xs, g, dn, true, li, q);
+        termination_residual_env<float>(eps_term, V, cst, dn, lt, r);
+        if (!valid) {   // padding lanes of the last tile contribute nothing
+            li = lt = r = 0.f;
+#pragma unroll
+            for (int k = 0; k < N; ++k) q[k] = 0.f;
+        }
+        if (h == 0 && valid) { acc_h += (double)li; acc_t += (double)lt; acc_ni += 1.0 - (double)dn; acc_nd += (double)dn; }
+        float gzb[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) gzb[k] = q[k] * p.istd[k];
+        if (h == 0) {
+            float rec[kSmallW];
+#pragma unroll
+            for (int k = 0; k < kSmallW; ++k) rec[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < N; ++k) { rec[k] = z[k]; rec[N + k] = gzb[k]; }
+            rec[2 * N] = r;
+            float4* sp = reinterpret_cast<float4*>(tb + kSmallOff + i * kSmallW);
+#pragma unroll
+            for (int k = 0; k < kSmallW / 4; ++k) sp[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+        }
+
+        // ---- reverse sweep of the input gradient with the cotangent q --------------------------------------------------------
+        f32x16 t1[1][4];
+        zero_acc(t1);
+        mfma_chain<OffW1F, N / 2, 4, 2, 1>(t1, ring4, c.w1f, [&](int st, int) { return h ? gzb[2 * st + 1] : gzb[2 * st]; });
+        relu_mask_apply(t1[0], m1);
+        store_tile_array<4>(tb, A_DH1B, t1[0], i, h);
+        f32x16 t2[1][4];
+        zero_acc(t2);
+        mfma_chain<OffW2F, 64, 4, 2, 1>(t2, ring4, c.w2f, [&](int st, int) { return t1[0][st >> 4][st & 15]; });
+        relu_mask_apply(t2[0], m2);
+        store_tile_array<4>(tb, A_DH2B, t2[0], i, h);
+        f32x16 t3[1][2];
+        zero_acc(t3);
+        mfma_chain<OffW3F, 64, 2, 2, 1>(t3, ring2, c.w3f, [&](int st, int) { return t2[0][st >> 4][st & 15]; });
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) t3[0][ob][rr] += t3[0][ob][rr];   // yb = 2 W3' dh2b
+        store_tile_array<2>(tb, A_YB, t3[0], i, h);
+        f32x16 t4[1][4];
+        zero_acc(t4);
+        mfma_chain<OffW3B, 32, 4, 2, 1>(t4, ring4, c.w3b, [&](int st, int) { return t3[0][st >> 4][st & 15]; });
+        relu_mask_apply(t4[0], m2);
+        store_tile_array<4>(tb, A_A2B, t4[0], i, h);
+        f32x16 t5[1][4];
+        zero_acc(t5);
+        mfma_chain<OffW2B, 64, 4, 2, 1>(t5, ring4, c.w2b, [&](int st, int) { return t4[0][st >> 4][st & 15]; });
+        relu_mask_apply(t5[0], m1);
+        store_tile_array<4>(tb, A_A1B, t5[0], i, h);
+    }
+    // loss sums and counts of this workgroup: lanes -> wave (shuffle tree) -> LDS -> one record (fixed order: deterministic)
+    acc_h = wave_sum_d(acc_h); acc_t = wave_sum_d(acc_t); acc_ni = wave_sum_d(acc_ni); acc_nd = wave_sum_d(acc_nd);
+    if (lane == 0) { red[0][wave] = acc_h; red[1][wave] = acc_t; red[2][wave] = acc_ni; red[3][wave] = acc_nd; }
+    __syncthreads();
+    if (tid < 4) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += red[tid][w];
+        sums_rec[4 * (int64_t)blockIdx.x + tid] = s;
+    }
+}
+
+// ---- kernel 2: the outer products, summed over the samples ------------------------------------------------------------------
+// LDS image of a half tile (16 samples): every group [16 samples][4 features] padded to kGS floats so that the operand read of lane
+// (i, k) -- group i >> 2, feature i & 3, sample 2 s + k -- hits 32 distinct banks per lane half; then the small records.
+static constexpr int kGS = 16 * 4 + 4;
+static constexpr int kHalfFloats = kTileGroups * kGS + 16 * kSmallW;   // 20096 floats = 80,384 bytes; two buffers = 160,768 bytes
+static constexpr int kBlocksPerSet = 4 + 16 + 8;                       // W1: 4 column blocks; W2: 4 x 4; W3: 4 x 2
+static constexpr int kBlocks = 2 * kBlocksPerSet;
+
+template <int N>
+__global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict__ scratch, float* __restrict__ partial, int64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    constexpr int NLD = (kTileGroups * 16 + 511) / 512;   // float4 loads per thread and half tile (groups), + 1 for the small records
+    float4 stage[NLD + 1];
+    auto issue = [&](int64_t tile, int hf) __attribute__((always_inline)) {
+        const float* tb = scratch + tile * (int64_t)kTileFloats;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + 512 * k;
+            if (f < kTileGroups * 16) stage[k] = *reinterpret_cast<const float4*>(tb + (f >> 4) * kGroupFloats + hf * 64 + (f & 15) * 4);
+        }
+        if (tid < 16 * kSmallW / 4) stage[NLD] = *reinterpret_cast<const float4*>(tb + kSmallOff + hf * 16 * kSmallW + tid * 4);
+    };
+    auto commit = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int f = tid + 512 * k;
+            if (f < kTileGroups * 16) *reinterpret_cast<float4*>(buf + (f >> 4) * kGS + (f & 15) * 4) = stage[k];
+        }
+        if (tid < 16 * kSmallW / 4) *reinterpret_cast<float4*>(buf + kTileGroups * kGS + tid * 4) = stage[NLD];
+    };
+    // operand of lane (i, kh) for block row/column `fb` of array `a` at k-step s of a half tile
+    const int lane_off = (i >> 2) * kGS + kh * 4 + (i & 3);
+    auto opnd = [&](const float* buf, int a, int fb, int s) { return buf[(group0(a) + fb * 8) * kGS + lane_off + s * 8]; };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const int64_t nmine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t nhalf = 2 * nmine;
+    if (nhalf > 0) {
+        issue(blockIdx.x, 0);
+        commit(lds);
+    }
+    __syncthreads();
+    for (int64_t ht = 0; ht < nhalf; ++ht) {
+        const float* buf = lds + (ht & 1) * kHalfFloats;
+        const bool more = ht + 1 < nhalf;
+        if (more) issue(blockIdx.x + ((ht + 1) >> 1) * gridDim.x, (int)((ht + 1) & 1));
+        const float* small = buf + kTileGroups * kGS;
+        if (wave < 4) {
+            // waves 0-3: row block ib = wave of dW2 -- acc[0..3] hjb set, acc[4..7] termination set
+            const int ib = wave;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float aD = opnd(buf, A_DH1B, ib, s), aH = opnd(buf, A_H1, ib, s);
+                const float rr = small[(2 * s + kh) * kSmallW + 2 * N];
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const float bD = opnd(buf, A_D2, jb, s), bA = opnd(buf, A_A2B, jb, s);
+                    acc[jb] = MFMA(aD, bD, acc[jb]);
+                    acc[jb] = MFMA(aH, bA, acc[jb]);
+                    acc[4 + jb] = MFMA(aH, rr * bD, acc[4 + jb]);
+                }
+            }
+        } else {
+            // waves 4-7: row block ib = wave - 4 of dW3 (acc[0..1] hjb, acc[2..3] termination) and column block jb = wave - 4 of dW1
+            // (acc[4] hjb, acc[5] termination; only the first N rows of that block are meaningful)
+            const int ib = wave - 4;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float aD = opnd(buf, A_DH2B, ib, s), aH = opnd(buf, A_H2, ib, s);
+                const float* rec = small + (2 * s + kh) * kSmallW;
+                const float rr = rec[2 * N];
+                const int ci = i < N ? i : 0;                       // rows >= N of the dW1 blocks are padding: zero operands
+                const float az = i < N ? rec[ci] : 0.f;
+                const float ag = i < N ? rec[N + ci] : 0.f;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const float bD = opnd(buf, A_DY, jb, s), bY = opnd(buf, A_YB, jb, s);
+                    acc[jb] = MFMA(aD, bD, acc[jb]);
+                    acc[jb] = MFMA(aH, bY, acc[jb]);
+                    acc[2 + jb] = MFMA(aH, rr * bD, acc[2 + jb]);
+                }
+                const float b1 = opnd(buf, A_D1, ib, s), bA1 = opnd(buf, A_A1B, ib, s);
+                acc[4] = MFMA(ag, b1, acc[4]);
+                acc[4] = MFMA(az, bA1, acc[4]);
+                acc[5] = MFMA(az, rr * b1, acc[5]);
+            }
+        }
+        if (more) commit(lds + ((ht + 1) & 1) * kHalfFloats);
+        __syncthreads();
+    }
+    // partial sums of this workgroup, raw accumulator layout [block][register][lane]
+    float* out = partial + (int64_t)blockIdx.x * kBlocks * 1024;
+    auto put = [&](int blk, const f32x16& a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[blk * 1024 + r * 64 + lane] = a[r];
+    };
+    if (wave < 4) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) { put(4 + wave * 4 + jb, acc[jb]); put(kBlocksPerSet + 4 + wave * 4 + jb, acc[4 + jb]); }
+    } else {
+        const int ib = wave - 4;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) { put(20 + ib * 2 + jb, acc[jb]); put(kBlocksPerSet + 20 + ib * 2 + jb, acc[2 + jb]); }
+        put(ib, acc[4]);
+        put(kBlocksPerSet + ib, acc[5]);
+    }
+}
+
+// ---- kernel 3: partial sums -> flat gradient buffer, in workgroup order ------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ partial, int nparts, const double* __restrict__ sums_rec, int nrec,
+                                                     float* __restrict__ flat) {
+    constexpr int P = N * kH1 + kH1 * kH2 + kH2 * kH3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < kBlocks * 1024) {
+        float s = 0.f;
+        for (int gI = 0; gI < nparts; ++gI) s += partial[(int64_t)gI * kBlocks * 1024 + t];
+        const int blk = t >> 10, reg = (t >> 6) & 15, lane = t & 63;
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+        const int set = blk / kBlocksPerSet, b = blk % kBlocksPerSet;
+        float* o = flat + set * P;
+        if (b < 4) {
+            if (row < N) o[row * kH1 + 32 * b + col] = s;
+        } else if (b < 20) {
+            o[N * kH1 + (32 * ((b - 4) >> 2) + row) * kH2 + 32 * ((b - 4) & 3) + col] = s;
+        } else {
+            o[N * kH1 + kH1 * kH2 + (32 * ((b - 20) >> 1) + row) * kH3 + 32 * ((b - 20) & 1) + col] = s;
+        }
+    } else if (t < kBlocks * 1024 + 4) {
+        const int k = t - kBlocks * 1024;
+        double s = 0;
+        for (int w = 0; w < nrec; ++w) s += sums_rec[4 * w + k];
+        flat[2 * P + k] = (float)s;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+static int device_cus() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+
+struct TrainWs { size_t scratch, partial, sums, total; int64_t ntiles; int n_cu; };
+static TrainWs train_ws(int64_t B) {
+    TrainWs w{};
+    w.n_cu = device_cus();
+    if (w.n_cu <= 0) w.n_cu = 256;
+    w.ntiles = (B + 31) / 32;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    w.scratch = up((size_t)w.ntiles * kTileFloats * sizeof(float));
+    w.partial = up((size_t)w.n_cu * kBlocks * 1024 * sizeof(float));
+    w.sums = up((size_t)w.n_cu * 4 * sizeof(double));
+    w.total = w.scratch + w.partial + w.sums;
+    return w;
+}
+
+template <typename S>
+static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
+                        const float* done, float* flat, void* workspace, int64_t B, void* st) {
+    constexpr int N = S::N, M = S::M;
+    if constexpr (N % 2 != 0 || 2 * N + 1 > kSmallW) {
+        return HJBX_EUNSUPPORTED;
+    } else {
+        MlpP<N> p;
+        for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.istd[k] = (float)(1.0 / mlp->std[k]); p.xf[k] = (float)mlp->xf[k]; }
+        p.eps_s = (float)mlp->eps_scalar;
+        const auto tk = make_task<float, N, M>(task);
+        const auto lim = make_limits<float, M>(sysh);
+        const TrainWs w = train_ws(B);
+        if (device_cus() <= 0) return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_loss_grad_f32: no HIP device");
+        float* scratch = (float*)workspace;
+        float* partial = (float*)((char*)workspace + w.scratch);
+        double* sums = (double*)((char*)workspace + w.scratch + w.partial);
+        const int gridA = (int)(w.ntiles < w.n_cu ? w.ntiles : w.n_cu);
+        const int gridB = gridA;
+        const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
+        hipStream_t s = (hipStream_t)st;
+        if (mode == HJBX_RESIDUAL_NORMALISED)
+            hipLaunchKernelGGL((k_train_chains<0, S, kTrWaves>), dim3(gridA), dim3(kTrWaves * 64), 0, s, sys, p, tk, lim, W1, W2, W3, x, cost, done,
+                               (float)task->eps, scratch, sums, B, w.ntiles);
+        else
+            hipLaunchKernelGGL((k_train_chains<1, S, kTrWaves>), dim3(gridA), dim3(kTrWaves * 64), 0, s, sys, p, tk, lim, W1, W2, W3, x, cost, done,
+                               (float)task->eps, scratch, sums, B, w.ntiles);
+        static bool attr_set = false;   // 160,768 bytes of dynamic LDS need the opt-in once per kernel
+        const size_t lds_bytes = 2 * (size_t)kHalfFloats * sizeof(float);
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_train_outer<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: cannot reserve %zu bytes of LDS", lds_bytes);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_train_outer<N>), dim3(gridB), dim3(512), lds_bytes, s, scratch, partial, w.ntiles);
+        const int nthreads = kBlocks * 1024 + 4;
+        hipLaunchKernelGGL((k_train_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, gridB, sums, gridA, flat);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: %s", hipGetErrorString(e));
+        return HJBX_OK;
+    }
+}
+
+extern "C" size_t hjbx_value_loss_grad_workspace_bytes(int64_t B) { return B > 0 ? train_ws(B).total : 0; }
+
+extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
+                                        const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream) {
+    if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: NULL system, task or mlp descriptor");
+    if (int rc = check_task(task)) return rc;
+    if (mode != HJBX_RESIDUAL_NORMALISED && mode != HJBX_RESIDUAL_RAW) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: unknown residual mode %d", mode);
+    if (B < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: negative batch size");
+    if (!flat) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: flat output buffer is NULL");
+    const size_t P = (size_t)sys->n * kH1 + (size_t)kH1 * kH2 + (size_t)kH2 * kH3;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(flat, 0, (2 * P + 4) * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        return HJBX_OK;
+    }
+    if (!x || !cost || !done || !workspace || !mlp->W1 || !mlp->W2 || !mlp->W3)
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x, cost, done, workspace and the weights must be non-NULL");
+    if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2, mlp->h3);
+    if (mlp->activation != HJBX_ACT_RELU)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: the fused parameter-gradient kernels exist for the relu network (controller/vhjb.py) only");
+    const size_t row = (size_t)sys->n * sizeof(float);
+    const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
+    if ((reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x must be aligned to its row vector width and workspace to 256 bytes");
+    for (int k = 0; k < sys->n; ++k)
+        if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: normalization_std[%d] is zero", k);
+    int rc = HJBX_EUNSUPPORTED;
+#ifdef HJBX_TRAIN_DEV   // development builds: cartpole only (the full set of instantiations takes minutes to compile)
+    bool ok = false;
+    if (sys->kind == HJBX_SYS_CARTPOLE) {
+        Cartpole<float> cp{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
+        rc = launch_train<Cartpole<float>>(sys, cp, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+        ok = true;
+    }
+#else
+    const bool ok = with_system<float>(sys, [&](auto S) { rc = launch_train<decltype(S)>(sys, S, task, mlp, mode, x, cost, done, flat, workspace, B, stream); });
+#endif
+    if (!ok || rc == HJBX_EUNSUPPORTED)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
+    return rc;
+}

@@ -33,7 +33,8 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5                      # BASELINE.json north_star: "trajectories matching the CPU reference to rtol 1e-5"
 DELTA = 1e-3                     # (ii): margin to the observation box, in error-coordinate units
-KINK = 1e-4                      # (i): an environment is "at a kink" when some hidden pre-activation has |a| < KINK * (sum of |terms| of that unit)
+KINK = 1e-5                      # (i): an environment is "at a kink" when some hidden pre-activation has |a| < KINK * (sum of |terms| of that unit);
+                                 #      float32 accumulation of a 128-term pre-activation is good to ~1e-6 of that sum (worst case 128 x 6e-8 = 8e-6)
 FULL = {"cartpole": 1 << 20, "quad2d": 1 << 18, "nearhover": 1 << 20}   # configs[1], [3], [4]
 _report = {}
 
@@ -172,7 +173,7 @@ def test_teacher_forced_single_step_per_element(name, weights):
     print(f"\n[f32 parity (i)] {name} {weights} B={B}: {at_kink.mean():.3%} of the environments within {KINK:g} of a ReLU kink (not compared); the rest: " +
           "; ".join(f"{k}: max err {v['max_err']:.2e}, p99.9 {v['p999_err']:.2e}, max err/bound {v['max_ratio']:.3f} "
                     f"[{v['beyond_bound_at_kinks']} at-kink envs beyond the bound, max {v['max_err_at_kinks']:.1e}]" for k, v in q.items()))
-    assert at_kink.mean() < 0.05
+    assert at_kink.mean() < 0.02
     for k, v in q.items():
         assert v["max_ratio"] <= 1.0, f"{k}: max err/bound {v['max_ratio']:.2f} away from the kinks; worst element {v['worst']}"
 

@@ -1,0 +1,164 @@
+"""GPU tests of hjbx_value_loss_grad_f32 -- the fused MFMA parameter gradient of the value-learning step (reference
+controller/vhjb.py:227-253, 282-284): forward, input gradient, the two residuals and the second-order reverse sweep in closed form.
+
+The reference's own version is jax.grad of a function of jax.grad (JAX not importable here: PARITY UNPINNED).  The checks are
+against an INDEPENDENT restatement: float64 torch.autograd double back-prop of the plain loss formulas on the same float32 weights
+(rtol 1e-4 on the gradient, the tolerance VERDICT r1 item 3 set), plus size-independent properties (additivity over the batch, bitwise
+reproducibility, zero contribution of done / padding samples) at sizes the restatement is not run at."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SYSTEMS
+from q_learning_with_hjb_amd import _abi, _ops
+from test_gpu_vhjb import _autograd_losses, controller, states_near_target
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(d, ctl, B, seed, frac=0.6, p_done=0.3):
+    xs = states_near_target(d, ctl, B, seed, frac)
+    rng = np.random.default_rng(seed + 100)
+    dones = torch.as_tensor((rng.uniform(size=B) < p_done).astype(np.float32), device="cuda")
+    costs = torch.as_tensor(rng.uniform(0.5, 20, B).astype(np.float32), device="cuda")
+    return xs, dones, costs
+
+
+def _reference_sums_f64(name, ctl32, xs, dones, costs, mode=_abi.RESIDUAL_NORMALISED):
+    """float64 autograd double back-prop of the loss SUMS on the float32 weights -> (g_h list, g_t list, scalars)"""
+    d64, ctl64 = controller(name, torch.float64, residual_mode=mode)
+    with torch.no_grad():
+        for w64, w32 in zip(ctl64.value_function_approximator.weights, ctl32.value_function_approximator.weights):
+            w64.copy_(w32.double())
+    x64, dn64, c64 = xs.double(), dones.double(), costs.double()
+    params = list(ctl64.value_function_approximator.parameters())
+    if mode == _abi.RESIDUAL_NORMALISED:
+        h, t = _autograd_losses(ctl64, x64, dn64, c64)          # means: multiply the normalisers back
+        n_int, n_done = float((1 - dn64).sum()), float(dn64.sum())
+        hs, ts = h * (n_int + ctl64.epsilon), t * (n_done + ctl64.epsilon)
+    else:
+        hs, hsums = ctl64._hjb_sums(x64, dn64)
+        ts, _ = ctl64._termination_sums(x64, dn64, c64)
+        n_int, n_done = float(hsums[1]), float(hsums[2])
+    g_h = torch.autograd.grad(hs, params, retain_graph=True, allow_unused=True)
+    g_t = torch.autograd.grad(ts, params, allow_unused=True)
+    z = lambda g, p: torch.zeros_like(p) if g is None else g
+    return [z(g, p) for g, p in zip(g_h, params)], [z(g, p) for g, p in zip(g_t, params)], (float(hs), float(ts), n_int, n_done)
+
+
+def _unpack(flat, n):
+    P1, P2, P3 = n * 128, 128 * 128, 128 * 64
+    P = P1 + P2 + P3
+    f = flat.double().cpu().numpy()
+    sets = []
+    for s in range(2):
+        o = s * P
+        sets.append([f[o:o + P1].reshape(n, 128), f[o + P1:o + P1 + P2].reshape(128, 128), f[o + P1 + P2:o + P].reshape(128, 64)])
+    return sets[0], sets[1], f[2 * P:]
+
+
+@pytest.mark.parametrize("B", [1, 33, 256, 1000])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_value_loss_grad_vs_f64_autograd(name, B):
+    """float32 MFMA kernels vs float64 autograd double back-prop: every gradient matrix to 1e-4 of its largest entry (per element) and
+    1e-4 in the Frobenius norm; loss sums to 1e-5; counts exact.  B = 1 / 33 / 1000 exercise padding lanes and partial tiles."""
+    d, ctl = controller(name)
+    vf = ctl.value_function_approximator
+    with torch.no_grad():
+        for w in vf.weights:
+            w.mul_(1.3)
+    xs, dones, costs = _batch(d, ctl, B, 31)
+    flat = _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs, costs, dones)
+    torch.cuda.synchronize()
+    gh, gt, sc = _unpack(flat, d.state_dim)
+    rh, rt, rsc = _reference_sums_f64(name, ctl, xs, dones, costs)
+    assert sc[2] == rsc[2] and sc[3] == rsc[3]
+    assert abs(sc[0] - rsc[0]) <= 1e-5 * abs(rsc[0]) + 1e-6 and abs(sc[1] - rsc[1]) <= 1e-5 * abs(rsc[1]) + 1e-6, (sc, rsc)
+    for label, got, want in (("hjb", gh, rh), ("termination", gt, rt)):
+        for k, (a, b) in enumerate(zip(got, want)):
+            b = b.cpu().numpy()
+            scale = np.abs(b).max()
+            if scale == 0:
+                assert np.abs(a).max() == 0
+                continue
+            err = np.abs(a - b)
+            assert err.max() <= 1e-4 * scale, f"{label} dW{k + 1}: max err {err.max():.3e} vs scale {scale:.3e} (rel {err.max() / scale:.2e})"
+            assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), f"{label} dW{k + 1}: Frobenius rel {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
+
+
+@pytest.mark.parametrize("name", ["cartpole", "quad2d"])
+def test_value_loss_grad_raw_residual_mode(name):
+    """HJBX_RESIDUAL_RAW (|gradV.xdot + l|, examples/cartpole_balancing.ipynb cell 11) against autograd through the f64 HIP residual op."""
+    d, ctl = controller(name, residual_mode=_abi.RESIDUAL_RAW)
+    vf = ctl.value_function_approximator
+    xs, dones, costs = _batch(d, ctl, 300, 5)
+    flat = _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs, costs, dones, mode=_abi.RESIDUAL_RAW)
+    gh, gt, sc = _unpack(flat, d.state_dim)
+    rh, rt, rsc = _reference_sums_f64(name, ctl, xs, dones, costs, mode=_abi.RESIDUAL_RAW)
+    assert abs(sc[0] - rsc[0]) <= 1e-5 * abs(rsc[0]) + 1e-6
+    for a, b in zip(gh + gt, rh + rt):
+        b = b.cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-30)
+
+
+def test_value_loss_grad_properties_at_scale():
+    """B = 2^17 + 77 (more tiles than workgroups, ragged tail): (a) bitwise reproducible, (b) additive over a split of the batch,
+    (c) samples marked done contribute nothing to the hjb set and only they contribute to the termination set."""
+    d, ctl = controller("cartpole")
+    vf = ctl.value_function_approximator
+    B = (1 << 17) + 77
+    xs, dones, costs = _batch(d, ctl, B, 9, frac=0.8)
+    n = d.state_dim
+    P = n * 128 + 128 * 128 + 128 * 64
+    call = lambda sl: _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs[sl].contiguous(), costs[sl].contiguous(), dones[sl].contiguous())
+    full = call(slice(None))
+    again = call(slice(None))
+    assert torch.equal(full, again)
+    k = 50011
+    parts = call(slice(0, k)).double() + call(slice(k, B)).double()
+    err = (full.double() - parts).abs()
+    scale = torch.stack([full[:P].abs().max(), full[P:2 * P].abs().max()]).double()
+    assert float(err[:P].max()) <= 2e-5 * float(scale[0]) and float(err[P:2 * P].max()) <= 2e-5 * float(scale[1])
+    assert float(err[2 * P:2 * P + 2].max()) <= 1e-5 * float(full[2 * P:2 * P + 2].abs().max())
+    assert torch.equal(full[2 * P + 2:], parts[2 * P + 2:].float())            # the counts are exact
+    assert float(full[2 * P + 2] + full[2 * P + 3]) == B
+    live = dones == 0
+    only_live = _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs[live].contiguous(), costs[live].contiguous(), dones[live].contiguous())
+    assert float(only_live[P:2 * P].abs().max()) == 0.0 and float(only_live[2 * P + 1]) == 0.0
+    assert float((only_live[:P].double() - full[:P].double()).abs().max()) <= 2e-5 * float(scale[0])
+
+
+def test_fused_and_autograd_updates_agree():
+    """params_update through the fused kernels == params_update through PyTorch autograd (same float32 data): losses to 1e-5, the
+    first Adam step's parameter change to 1e-3 of the step size except where |g| ~ Adam's eps."""
+    res = {}
+    for fused in (True, False):
+        d, ctl = controller("cartpole", fused_param_grad=fused, graph_updates=False)
+        assert ctl.fused_param_grad == fused
+        xs, dones, costs = _batch(d, ctl, 256, 3)
+        before = [p.detach().clone() for p in ctl.value_function_approximator.parameters()]
+        tot, h, t = ctl.params_update(xs, dones, costs, 0.37)
+        res[fused] = (float(tot), float(h), float(t), [(p.detach() - b) for p, b in zip(ctl.value_function_approximator.parameters(), before)],
+                      [p.grad.detach().clone() for p in ctl.value_function_approximator.parameters()])
+    a, b = res[True], res[False]
+    for k in range(3):
+        assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-7
+    for ga, gb in zip(a[4], b[4]):
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+    for da, db, gb in zip(a[3], b[3], b[4]):
+        big = gb.abs() > 1e-5                                    # away from Adam's eps the first step is -lr sign(g)
+        assert float((da - db)[big].abs().max()) <= 1e-6
+
+
+def test_value_loss_grad_rejects_what_it_cannot_do():
+    d, ctl = controller("cartpole", activation="tanh")
+    xs, dones, costs = _batch(d, ctl, 64, 1)
+    with pytest.raises(NotImplementedError):
+        _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs, costs, dones)
+    assert not ctl.fused_param_grad                              # the controller falls back to autograd for tanh on its own
+    with pytest.raises(NotImplementedError):
+        controller("cartpole", activation="tanh", fused_param_grad=True)
+    d, ctl = controller("cartpole")
+    flat = _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs[:0].contiguous(), costs[:0].contiguous(),
+                                dones[:0].contiguous())
+    assert float(flat.abs().max()) == 0.0
