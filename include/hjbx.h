@@ -96,8 +96,10 @@ typedef enum hjbx_option {
     HJBX_OPT_ROLLOUT_SCHEDULE = 0,         /* work distribution of hjbx_vhjb_rollout_f32: 0 (default) = equal static shares per workgroup, with
                                               the shares of workgroups that have not started taken over by the waves that finish first;
                                               1 = device-wide tile queue (one atomic per 32-environment tile) */
-    HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS = 1  /* TEST HOOK: launch this many workgroups more than there are CUs (they cannot be resident until
+    HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS = 1, /* TEST HOOK: launch this many workgroups more than there are CUs (they cannot be resident until
                                               others finish -- the situation the take-over above exists for); default 0 */
+    HJBX_OPT_STREAM_ROWS = 2               /* TUNING: rows per thread of the float32 streaming kernels (simulate, vhjb_step, hjb_residual):
+                                              1, 2 or 4; 0 (default) = the library's choice */
 } hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */

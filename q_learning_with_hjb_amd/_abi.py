@@ -24,7 +24,7 @@ LAW_QUADRATIC, LAW_BANGBANG = 0, 1
 ACT_RELU, ACT_TANH, ACT_SIN = 0, 1, 2
 ROLLOUT_TERMINATE = 1
 ROLLOUT_STOP_AT_TARGET = 2
-OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS = 0, 1
+OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS, OPT_STREAM_ROWS = 0, 1, 2
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")

@@ -34,8 +34,8 @@ int hjbx_set_error(int code, const char* fmt, ...) {
 }
 
 // process-wide knobs (include/hjbx.h: hjbx_option)
-static std::atomic<int> g_options[2] = {{0}, {0}};
-int hjbx_option_value(int option) { return (option >= 0 && option < 2) ? g_options[option].load(std::memory_order_relaxed) : 0; }
+static std::atomic<int> g_options[3] = {{0}, {0}, {0}};
+int hjbx_option_value(int option) { return (option >= 0 && option < 3) ? g_options[option].load(std::memory_order_relaxed) : 0; }
 
 #define HJBX_REQUIRE(cond, ...)                                  \
     do {                                                         \
@@ -89,7 +89,10 @@ static inline dim3 grid_rows(int64_t B, int R) { return dim3((unsigned)((B + (in
 // batches keep one row per thread (more workgroups); float64 keeps one row (its row state alone is 2x the registers)
 template <typename T> static inline int rows_per_thread(int64_t B, int n) {
     if (sizeof(T) != 4) return 1;
-    return B >= (1 << 19) ? (n <= 4 ? 4 : 2) : (B >= (1 << 17) ? 2 : 1);   // wide rows: 4 of them would cost a resident wave per SIMD
+    const int forced = hjbx_option_value(HJBX_OPT_STREAM_ROWS);
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    (void)B; (void)n;
+    return 1;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -305,13 +308,13 @@ template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, uns
 }
 
 // hjb_loss body (vhjb.py:227-241) + analytic d loss_i / d gradV
-template <int MODE, typename S, typename T>
+template <int MODE, int R, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim,
                                                          const T* __restrict__ x, const T* __restrict__ g,
                                                          const T* __restrict__ done, T* __restrict__ loss_i,
                                                          T* __restrict__ dl_dg, unsigned char* ws, T* __restrict__ sums, int64_t B) {
     constexpr int N = S::N;
-    constexpr int R = sizeof(T) == 4 ? (N <= 4 ? 4 : 2) : 1;   // rows in flight per thread (see k_simulate); the grid is capped at kReduceBlocks workgroups
+    // R rows in flight per thread (see k_simulate); the grid is capped at kReduceBlocks workgroups
     double acc_l = 0, acc_nb = 0, acc_nd = 0;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < B; i0 += R * stride) {
@@ -603,12 +606,19 @@ static int hjb_residual_impl(const hjbx_system* sys, const hjbx_task* task, int 
             using SS = decltype(S);
             auto tk = make_task<T, SS::N, SS::M>(task);
             auto lim = make_limits<T, SS::M>(sys);
-            if (mode == HJBX_RESIDUAL_NORMALISED)
-                hipLaunchKernelGGL((k_hjb_residual<0, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g,
-                                   done, loss_i, dl_dg, ws, sums, B);
-            else
-                hipLaunchKernelGGL((k_hjb_residual<1, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g,
-                                   done, loss_i, dl_dg, ws, sums, B);
+            auto go = [&](auto modec, auto rc) {
+                constexpr int MD = decltype(modec)::value, R = decltype(rc)::value;
+                hipLaunchKernelGGL((k_hjb_residual<MD, R, SS, T>), dim3(grid), dim3(kBlock), 0, (hipStream_t)st, S, tk, lim, x, g, done, loss_i, dl_dg,
+                                   ws, sums, B);
+            };
+            auto with_r = [&](auto modec) {
+                const int R = rows_per_thread<T>(B, SS::N);
+                if (R == 4) go(modec, std::integral_constant<int, 4>{});
+                else if (R == 2) go(modec, std::integral_constant<int, 2>{});
+                else go(modec, std::integral_constant<int, 1>{});
+            };
+            if (mode == HJBX_RESIDUAL_NORMALISED) with_r(std::integral_constant<int, 0>{});
+            else with_r(std::integral_constant<int, 1>{});
         })) return unsupported(sys);
     return check_launch("hjbx_hjb_residual");
 }
@@ -790,7 +800,7 @@ int hjbx_device_count(void) {
 }
 
 int hjbx_set_option(int option, int value) {
-    HJBX_REQUIRE(option == HJBX_OPT_ROLLOUT_SCHEDULE || option == HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS, "unknown option %d", option);
+    HJBX_REQUIRE(option == HJBX_OPT_ROLLOUT_SCHEDULE || option == HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS || option == HJBX_OPT_STREAM_ROWS, "unknown option %d", option);
     HJBX_REQUIRE(option != HJBX_OPT_ROLLOUT_SCHEDULE || value <= 1, "rollout schedule must be 0 or 1, got %d", value);
     HJBX_REQUIRE(value <= 64, "option value %d out of range", value);
     return value < 0 ? g_options[option].load() : g_options[option].exchange(value);

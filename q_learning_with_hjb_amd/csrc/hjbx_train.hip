@@ -67,7 +67,8 @@ __device__ __forceinline__ void relu_mask_build(const f32x16 (&hv)[4], uint32_t 
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t nz = __builtin_bit_cast(uint32_t, hv[fb][r]);
+            const float hf = hv[fb][r];   // (bit_cast applied directly to a vector ELEMENT expression miscompiles: clang 19 / ROCm 7.2)
+            const uint32_t nz = __builtin_bit_cast(uint32_t, hf);
             m[fb >> 1] |= (nz < 1u ? nz : 1u) << (16 * (fb & 1) + r);   // v_min_u32 + v_lshl_or_b32, no VCC
         }
 }
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
                                                                       double* __restrict__ sums_rec, int64_t B, int64_t ntiles) {
     constexpr int N = S::N, M = S::M, ACT = HJBX_ACT_RELU;
     constexpr int NP = MlpLds<N>::NP;
-    static_assert(N % 2 == 0 && 2 * N + 1 <= kSmallW, "state dimension");
+    static_assert(N % 2 == 0 && 3 * N + 1 <= kSmallW, "state dimension");
     __shared__ __attribute__((aligned(16))) MlpLds<N> L;
     __shared__ __attribute__((aligned(16))) unsigned char sys_raw[sizeof(S)];
     S& sys_s = *reinterpret_cast<S*>(sys_raw);
@@ -231,6 +232,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
 #pragma unroll
             for (int k = 0; k < N; ++k) { rec[k] = z[k]; rec[N + k] = gzb[k]; }
             rec[2 * N] = r;
+#pragma unroll
+            for (int k = 0; k < N; ++k) rec[2 * N + 1 + k] = g[k];   // (diagnostic only: dV/dx as this kernel computed it; k_train_outer ignores it)
             float4* sp = reinterpret_cast<float4*>(tb + kSmallOff + i * kSmallW);
 #pragma unroll
             for (int k = 0; k < kSmallW / 4; ++k) sp[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
@@ -450,7 +453,7 @@ template <typename S>
 static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
                         const float* done, float* flat, void* workspace, int64_t B, void* st) {
     constexpr int N = S::N, M = S::M;
-    if constexpr (N % 2 != 0 || 2 * N + 1 > kSmallW) {
+    if constexpr (N % 2 != 0 || 3 * N + 1 > kSmallW) {
         return HJBX_EUNSUPPORTED;
     } else {
         MlpP<N> p;

@@ -1,0 +1,90 @@
+"""GPU tests of properties the reference does not state as tests but fixes by construction or by printed outputs:
+  * the order of the integrators (forward Euler = the reference's, dynamics_basic.py:120; RK4 = this library's extra mode);
+  * the LQR baselines printed in the reference's notebooks, reproduced from the reference's own NumPy code and RNG stream by
+    tools/gen_notebook_pins.py (tests/golden/notebook_lqr.npz): trajectory-level cost accumulation through hjbx_rollout_feedback."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ANGLE_IDX, GOLDEN, make_dynamics, wrapped_diff
+from q_learning_with_hjb_amd import _abi, _ops
+from q_learning_with_hjb_amd.configs import defaults as D
+from q_learning_with_hjb_amd.dynamics.acrobot import Acrobot
+from q_learning_with_hjb_amd.dynamics.cartpole import Cartpole
+from q_learning_with_hjb_amd.dynamics.quadrotors import NearHoverQuadcopter, Quadrotors2D
+
+pytestmark = pytest.mark.gpu
+
+
+def _integrate(make, dt, integ, x0, u, t_end):
+    d = make(dt)
+    x = torch.as_tensor(x0, dtype=torch.float64, device="cuda").contiguous()
+    ut = torch.as_tensor(u, dtype=torch.float64, device="cuda").contiguous()
+    for _ in range(int(round(t_end / dt))):
+        x = _ops.simulate(d.system, x, ut, integ)
+    return x.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["cartpole", "acrobot", "quad2d", "nearhover"])
+def test_integrator_order_of_convergence(name):
+    """Global error at t = 0.32 under a constant control, f64 kernels, against a dt/64 RK4 reference: halving dt divides the RK4 error by
+    ~16 (4th order) and the Euler error by ~2 (1st order)."""
+    make = {"cartpole": lambda dt: Cartpole(D.cartpole_dynamics_config(dt=dt)), "acrobot": lambda dt: Acrobot(D.acrobot_dynamics_config(dt=dt)),
+            "quad2d": lambda dt: Quadrotors2D(D.quadrotors2d_dynamics_config(dt=dt)), "nearhover": lambda dt: NearHoverQuadcopter(D.near_hover_dynamics_config(dt=dt))}[name]
+    d0 = make(0.04)
+    n, m = d0.get_dimension()
+    rng = np.random.default_rng(2)
+    B = 64
+    x0 = rng.uniform(-0.6, 0.6, (B, n))
+    if name == "cartpole":
+        x0[:, 1] += 2.0                                        # away from the wrap seam at +-pi for the whole horizon
+    u = (np.asarray(d0.umin) + np.asarray(d0.umax)) / 2 + 0.3 * rng.uniform(-1, 1, (B, m)) * (np.asarray(d0.umax) - np.asarray(d0.umin)) / 2
+    t_end, dt = 0.32, 0.04
+    ref = _integrate(make, dt / 64, _abi.RK4, x0, u, t_end)
+    ai = ANGLE_IDX[name]
+    err = {}
+    for integ, label in ((_abi.RK4, "rk4"), (_abi.EULER, "euler")):
+        for k in (1, 2, 4):
+            err[label, k] = np.abs(wrapped_diff(_integrate(make, dt / k, integ, x0, u, t_end), ref, ai)).max()
+    r_rk4 = (err["rk4", 1] / err["rk4", 2], err["rk4", 2] / err["rk4", 4])
+    r_eul = (err["euler", 1] / err["euler", 2], err["euler", 2] / err["euler", 4])
+    print(f"\n{name}: RK4 errors {err['rk4', 1]:.2e} {err['rk4', 2]:.2e} {err['rk4', 4]:.2e} (ratios {r_rk4[0]:.1f}, {r_rk4[1]:.1f}); "
+          f"Euler {err['euler', 1]:.2e} {err['euler', 2]:.2e} {err['euler', 4]:.2e} (ratios {r_eul[0]:.2f}, {r_eul[1]:.2f})")
+    assert err["rk4", 1] < 1e-4 * max(1.0, np.abs(ref).max())
+    if err["rk4", 4] > 1e-13:                                   # (the near-hover model is linear except for tan: RK4 can already be at rounding)
+        assert 11 < r_rk4[0] < 22 and 11 < r_rk4[1] < 22
+    assert 1.7 < r_eul[0] < 2.4 and 1.7 < r_eul[1] < 2.4
+
+
+def _pins():
+    path = os.path.join(GOLDEN, "notebook_lqr.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/notebook_lqr.npz not generated")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", ["nearhover", "cartpole", "quad2d"])
+def test_notebook_lqr_baseline_costs(name):
+    """The LQR closed-loop costs the reference's notebooks PRINT (10D_quadcopte.ipynb cell 14: 9.085334056081662; see
+    tests/golden/notebook_lqr.json for which ones could be reproduced from the NumPy stream), through the fused f64 rollout kernel:
+    sum over T / dt steps of l(x_t, u_t) dt with u_t = clip(-K wrap(x_t - xf) + uf)."""
+    z = _pins()
+    if f"{name}_x0" not in z:
+        pytest.skip(f"the notebook's evaluation starts for {name} could not be reconstructed (tests/golden/notebook_lqr.json)")
+    d = make_dynamics(name)
+    n, m = d.get_dimension()
+    K, x0, want, T = z[f"{name}_K"], z[f"{name}_x0"], z[f"{name}_cost"], float(z[f"{name}_T"][0])
+    xf = {"nearhover": np.zeros(10), "cartpole": np.array([0, 3.1415926, 0, 0]), "quad2d": np.zeros(6)}[name]
+    uf = {"nearhover": np.array([9.81 * 1 / 0.91, 0, 0]), "cartpole": np.zeros(1), "quad2d": np.array([4.905, 4.905])}[name]
+    task = _abi.make_task(n, m, np.eye(n), np.eye(m), np.eye(n), xf, uf, None, None, 1e-10)
+    ctrl = _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, n, m, K, xf=xf, uf=uf, wrap_error=True)
+    steps = int(round(T / d.dt))
+    out = _ops.rollout_feedback(d.system, ctrl, torch.as_tensor(x0, dtype=torch.float64, device="cuda").contiguous(), steps, task=task, log_u=True)
+    got = out["total_cost"].cpu().numpy()
+    if name == "cartpole":                                       # that notebook's LQR law is not clipped before the cost is charged
+        assert float(out["u"].abs().max()) < 10.0
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    assert abs(got.mean() - want.mean()) < 1e-9 * want.mean()

@@ -1,0 +1,129 @@
+"""a18: the bookkeeping of VHJBController.train (reference controller/vhjb.py:290-343) against an oracle-side restatement.
+
+What is compared, epoch by epoch, with the optimiser step replaced by a recorder (the weights stay fixed, so every rollout is the
+oracle's f64 rollout from the same start states):
+  * replay buffer: a deque(maxlen) extended trajectory by trajectory with the emitted (x, cost, done) tuples (vhjb.py:62-73, 308) --
+    order, wrap-around and contents;
+  * minibatches: floor(len(buffer) / batch_size) per epoch (DataLoader(drop_last=True), :154), each a draw WITHOUT replacement from
+    the buffer as it stands after the epoch's rollouts (the permutation itself comes from torch's RNG in the reference and from a
+    device generator here: not comparable, and not compared);
+  * update_counter and the regularisation weight: one increment per minibatch, schedule re-evaluated after each (:323-324), the first
+    update using schedule(0) (:127-128);
+  * the six returned lists: lengths (loss lists only grow in epochs that had a minibatch, :331, 339) and the trajectory statistics
+    (mean cost, population std, mean length, :326-329).
+The restatement follows the reference text (JAX is not importable here: PARITY UNPINNED for this row)."""
+from collections import deque
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ANGLE_IDX, make_dynamics, make_vhjb_config, wrapped_diff
+from oracle import oracle as O
+from q_learning_with_hjb_amd.controller.vhjb import VHJBController, sgdr_schedule
+
+pytestmark = pytest.mark.gpu
+
+
+def _buffer_in_order(rb):
+    """logical (oldest -> newest) contents of the device ring"""
+    if rb.size < rb.capacity:
+        idx = torch.arange(rb.size, device=rb.x.device)
+    else:
+        idx = (rb.head + torch.arange(rb.capacity, device=rb.x.device)) % rb.capacity
+    return rb.x[idx].cpu().numpy(), rb.cost[idx].cpu().numpy(), rb.done[idx].cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["cartpole", "quad2d"])
+def test_train_bookkeeping_matches_reference_loop(name):
+    epochs, ntraj, T, batch, cap = 7, 6, 25, 64, 300
+    cfg = make_vhjb_config(name, epochs=epochs, num_of_trajectories_per_epoch=ntraj, maximum_step=T, batch_size=batch, maximum_buffer_size=cap,
+                           regularization_warmup_steps_per_cycle=3, regularization_total_steps_per_cycle=7, regularization_num_of_cycles=2,
+                           regularization_peak_value=1e-2)
+    d = make_dynamics(name)
+    ctl = VHJBController(d, cfg, dtype=torch.float64, graph_updates=False)
+    n = d.state_dim
+    # fixed start states for every epoch (both sides); a spread that makes some trajectories leave the box early
+    rng = np.random.default_rng(5)
+    box = np.asarray(cfg.obs_max, np.float64).clip(max=3.0)
+    starts = np.asarray(cfg.xf, np.float64) + rng.uniform(-1, 1, (epochs, ntraj, n)) * box * 1.02
+    starts = O.wrap(O.System.from_dynamics(d), starts.reshape(-1, n)).reshape(epochs, ntraj, n)
+    it = iter(starts)
+    d.get_initial_state = lambda batch_size=None, **kw: next(it)
+    seen = []
+
+    def recorder(xs, dones, costs, regularization):
+        x, c, dn = _buffer_in_order(ctl.replay_buffer)
+        seen.append(dict(xs=xs.cpu().numpy(), dones=dones.cpu().numpy(), costs=costs.cpu().numpy(), reg=float(regularization), counter=ctl.update_counter,
+                         buffer=(x.copy(), c.copy(), dn.copy())))
+        z = torch.zeros((), dtype=torch.float64, device=xs.device)
+        return z + 3.0, z + 1.0, z + 2.0                           # (total, hjb, termination) "losses" of the stub
+    ctl.params_update = recorder
+
+    # ---- the restatement --------------------------------------------------------------------------------------------------
+    x, c, dn = _buffer_in_order(ctl.replay_buffer)
+    assert len(x) == cfg.num_of_interior_data + cfg.num_of_boundary_data                # seed set (vhjb.py:136-150)
+    assert np.array_equal(dn, [0] * cfg.num_of_interior_data + [1] * cfg.num_of_boundary_data)
+    buf = deque(zip(x, c, dn), maxlen=cap)
+    vf = ctl.value_function_approximator
+    W = [w.detach().cpu().numpy() for w in vf.weights]
+    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar)
+    s = O.System.from_dynamics(d)
+    sched = dict(init_value=cfg.regularization_init_value, peak_value=cfg.regularization_peak_value, end_value=cfg.regularization_end_value,
+                 warmup_steps=cfg.regularization_warmup_steps_per_cycle, decay_steps=cfg.regularization_total_steps_per_cycle,
+                 num_cycles=cfg.regularization_num_of_cycles)
+    counter, want_calls, want_cost, want_std, want_len, want_loss_epochs = 0, [], [], [], [], 0
+    for ep in range(epochs):
+        ref = O.vhjb_rollout(s, ctl._task, mlp, *W, starts[ep], T)
+        costs = []
+        for b in range(ntraj):
+            L = int(ref["done_step"][b]) + 1
+            for t in range(L):
+                buf.append((ref["traj"][t, b], ref["cost"][t, b], 1.0 if t == L - 1 else 0.0))
+            costs.append(ref["cost"][:L, b].sum())
+        want_cost.append(sum(costs) / ntraj)
+        want_std.append(np.var(np.array(costs)) ** 0.5)
+        want_len.append((ref["done_step"] + 1).sum() / ntraj)
+        nb = len(buf) // batch
+        snapshot = (np.array([t[0] for t in buf]), np.array([t[1] for t in buf]), np.array([t[2] for t in buf]))
+        for _ in range(nb):
+            want_calls.append(dict(reg=sgdr_schedule(counter, **sched), counter=counter, buffer=snapshot))
+            counter += 1
+        want_loss_epochs += 1 if nb else 0
+
+    out = ctl.train()
+    # ---- compare ----------------------------------------------------------------------------------------------------------
+    assert ctl.update_counter == counter and len(seen) == len(want_calls) > 0
+    assert abs(ctl.regularization - sgdr_schedule(counter, **sched)) < 1e-15
+    ai = ANGLE_IDX[name]
+    for got, want in zip(seen, want_calls):
+        assert got["counter"] == want["counter"] and abs(got["reg"] - want["reg"]) < 1e-15
+        bx, bc, bd = want["buffer"]
+        gx, gc, gd = got["buffer"]
+        assert gx.shape == bx.shape and np.array_equal(gd, bd)                          # same length, same done pattern = same order
+        assert np.abs(wrapped_diff(gx, bx, ai)).max() < 1e-9 and np.abs(gc - bc).max() < 1e-9 * max(1.0, np.abs(bc).max())
+        # the minibatch: `batch` DISTINCT rows of that buffer (costs and done flags travelling with their states)
+        assert got["xs"].shape == (batch, n)
+        rows = []
+        for xr, cr, dr in zip(got["xs"], got["costs"], got["dones"]):
+            hit = np.nonzero((np.abs(gx - xr).max(1) == 0) & (gc == cr) & (gd == dr))[0]
+            assert hit.size >= 1
+            rows.append(tuple(hit))
+        assert len(set(rows)) >= batch - 2                                              # (identical duplicate records may exist in the buffer)
+    a_cost, a_std, a_len, l_tot, l_hjb, l_term = out
+    assert len(a_cost) == len(a_std) == len(a_len) == epochs and len(l_tot) == len(l_hjb) == len(l_term) == want_loss_epochs
+    np.testing.assert_allclose(a_cost, want_cost, rtol=1e-9)
+    np.testing.assert_allclose(a_std, want_std, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(a_len, want_len, rtol=0, atol=0)
+    assert all(abs(v - 3.0) < 1e-12 for v in l_tot) and all(abs(v - 1.0) < 1e-12 for v in l_hjb) and all(abs(v - 2.0) < 1e-12 for v in l_term)
+    assert len(ctl.replay_buffer) == min(cap, len(buf)) == cap                         # the deque wrapped around in this configuration
+
+
+def test_sgdr_schedule_follows_the_update_counter():
+    """schedule(0) = init for the first update; counter increments once per minibatch (vhjb.py:127-128, 323-324)."""
+    d = make_dynamics("cartpole")
+    ctl = VHJBController(d, make_vhjb_config("cartpole"), dtype=torch.float64, graph_updates=False)
+    assert ctl.update_counter == 0 and ctl.regularization == 0.0
+    vals = [ctl.regularization_scheduler(k) for k in (0, 500, 1000, 1500, 2000, 2001, 19999, 20000, 50000)]
+    assert vals[0] == 0.0 and abs(vals[1] - 0.5e-5) < 1e-18 and abs(vals[2] - 1e-5) < 1e-18 and abs(vals[3] - 0.5e-5) < 1e-12
+    assert vals[4] == 0.0 and 0 < vals[5] < 2e-8 and vals[7] == 0.0 and vals[8] == 0.0

@@ -251,3 +251,27 @@ def test_bang_bang_rollout_stops_in_the_target_ball_and_counts_time():
     # the two laws differ only on the switching curve itself (measure zero until chatter puts states next to it)
     assert np.abs(ds - ref["done_step"]).max() <= 30 and np.median(np.abs(ds - ref["done_step"])) <= 2
     close(total, ds * 0.01, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["nearhover", "cartpole", "quad2d"])
+def test_notebook_lqr_baseline_costs_pin_the_oracle(name):
+    """Numbers the reference's notebooks PRINT (10D_quadcopte.ipynb cell 14: `lqr cost 9.085334056081662`), reproduced from the
+    reference's NumPy dynamics and RNG stream by tools/gen_notebook_pins.py: whole closed loops with cost accumulation (a1 + a12 + a20)."""
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "notebook_lqr.npz")
+    with np.load(path) as zf:
+        z = {k: zf[k] for k in zf.files}
+    if f"{name}_x0" not in z:
+        pytest.skip(f"the notebook's evaluation starts for {name} could not be reconstructed (tests/golden/notebook_lqr.json)")
+    d = make_dynamics(name)
+    n, m = d.get_dimension()
+    xf = {"nearhover": np.zeros(10), "cartpole": np.array([0, 3.1415926, 0, 0]), "quad2d": np.zeros(6)}[name]
+    uf = {"nearhover": np.array([9.81 * 1 / 0.91, 0, 0]), "cartpole": np.zeros(1), "quad2d": np.array([4.905, 4.905])}[name]
+    task = _abi.make_task(n, m, np.eye(n), np.eye(m), np.eye(n), xf, uf, None, None, 1e-10)
+    ctrl = _abi.make_controller(_abi.CTRL_LINEAR_FEEDBACK, n, m, z[f"{name}_K"], xf=xf, uf=uf, wrap_error=True)
+    steps = int(round(float(z[f"{name}_T"][0]) / d.dt))
+    out = O.rollout_feedback(orc_system(name), ctrl, z[f"{name}_x0"], steps, task=task)
+    np.testing.assert_allclose(out["total_cost"], z[f"{name}_cost"], rtol=1e-10)
+    if name == "nearhover":
+        assert abs(out["total_cost"][0] - 9.085334056081662) < 1e-10

@@ -58,10 +58,20 @@ def main():
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--pool-mb", type=int, default=640)
     ap.add_argument("--no-rollouts", action="store_true", help="skip the fused closed-form rollouts (counter runs)")
+    ap.add_argument("--rows", type=int, default=0, help="HJBX_OPT_STREAM_ROWS: rows per thread of the streaming kernels (0 = library default)")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     B = args.batch
     rows = []
+    _abi.set_option(_abi.OPT_STREAM_ROWS, args.rows)
+    # reference point: a plain device copy of the same size class, timed the same way (rotating buffers)
+    nset = max(2, int(np.ceil(args.pool_mb * (1 << 20) / (8.0 * B * 4))))
+    cps = [dict(a=torch.randn((B, 4), device="cuda"), b=torch.empty((B, 4), device="cuda")) for _ in range(nset)]
+    secs = timed(lambda s: s["b"].copy_(s["a"]), cps)
+    rows.append(dict(system="-", kernel="torch copy 16 MB -> 16 MB", us=secs * 1e6, bytes_per_env=32, GBs=32 * B / secs / 1e9, frac_of_8TBs=32 * B / secs / 1e9 / 8000,
+                     env_steps_per_s=B / secs, rotating_sets=nset))
+    del cps
+    torch.cuda.empty_cache()
     for name in args.systems.split(","):
         d = make_dynamics(name)
         cfg = make_vhjb_config(name)
