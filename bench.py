@@ -319,7 +319,7 @@ def param_gradient_kernels(system="nearhover", B=1 << 20):
     ach = flops * B / t / 1e12
     return dict(name=f"value_loss_grad: parameter gradient of the learning step ({system}, B=2^{int(np.log2(B))})", ms=t * 1e3, samples_per_s=B / t,
                 achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TFLOPS, bound="mfma", flop_per_sample=flops,
-                scratch_bytes_per_sample=2 * 4.0 * 37888 / 32)
+                scratch_bytes_per_sample=2 * 4.0 * 40960 / 32)
 
 
 def optimiser_step(world, dist):

@@ -16,14 +16,14 @@
 // Two kernels, because the two halves want opposite register layouts:
 //  * k_train_chains -- every matrix-vector product above as an MFMA chain, one 32-sample tile per wave, exactly like the inference
 //    kernel (features x samples: a layer's accumulators are the next chain's B operands, weights in LDS).  It writes the twelve
-//    operand arrays of the outer products to a scratch buffer, 4.7 KB per sample.
+//    operand arrays of the outer products to a scratch buffer, 5 KB per sample, laid out as the LDS images of the second kernel.
 //  * k_train_outer -- the outer products are GEMMs whose contraction index is the SAMPLE, so both operands need the feature on the
-//    lane.  One workgroup per CU streams tiles of the scratch through LDS (double buffered half tiles) and its 8 waves own the 56
+//    lane.  One workgroup per CU streams the scratch through LDS by LDS-DMA (two 80-KiB half-tile images) and its 8 waves own the 56
 //    32x32 output blocks (hjb + termination sets of W1, W2, W3) as MFMA accumulators for the whole launch; per-workgroup partial
 //    sums go to the workspace and k_train_reduce adds them in workgroup order (deterministic, no float atomics) into the flat
 //    buffer [dW1_h | dW2_h | dW3_h | dW1_t | dW2_t | dW3_t | sum l_h, sum l_t, #interior, #done] -- the layout of the single
 //    all-reduce of the data-parallel step (controller/vhjb.py: pack_flat).
-// Scratch traffic (written once, read once) is 9.5 KB per sample against 0.37 Mflop: both kernels stay MFMA bound.
+// Scratch traffic (written once, read once) is 10 KB per sample against 0.36 Mflop: both kernels stay MFMA bound.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -36,26 +36,46 @@ using namespace hjbx;
 
 static constexpr int kTrWaves = 8;
 
-// ---- scratch layout of one 32-sample tile (floats) --------------------------------------------------------------------------
-// A 128-feature array is 32 groups of [32 samples][4 features]: group (fb, q, hh) holds features 32 fb + 8 q + 4 hh + 0..3, i.e.
-// exactly the four accumulator registers 4q..4q+3 of block fb in lane half hh -- one coalesced float4 store per lane and group.
+// ---- scratch layout ----------------------------------------------------------------------------------------------------------
+// Per 32-sample tile TWO images, one per half tile (16 samples); an image is byte for byte the LDS image k_train_outer consumes, so it
+// is copied by LDS-DMA (global_load_lds_dwordx4: 80 wave-wide 1-KiB pieces, no registers, no ds_write).  A 128-feature array is 32
+// groups of [16 sample slots][4 features]: group (fb, q, hh) holds features 32 fb + 8 q + 4 hh + 0..3 = the accumulator registers
+// 4q..4q+3 of block fb in lane half hh, one float4 per sample.  Sample e sits in slot (e & 15) ^ (2 q + hh): with that XOR the operand
+// read of k_train_outer -- lanes = 32 consecutive features (8 groups x 4), one sample -- hits 32 distinct LDS banks without padding
+// (an LDS-DMA image must be lane-linear, so padding is not available: guide 5, Caveat; rule 21: swizzle on both sides).
 enum { A_H1 = 0, A_DH1B, A_D2, A_A2B, A_H2, A_DH2B, A_D1, A_A1B, A_DY, A_YB, A_COUNT };
-static constexpr int kGroupFloats = 32 * 4;
 static constexpr int kGroups128 = 32, kGroups64 = 16;
-static constexpr int kTileGroups = 8 * kGroups128 + 2 * kGroups64;      // 288
-static constexpr int kSmallW = 32;                                      // per sample: z (n), gzb (n), r, zero padding
-static constexpr int kSmallOff = kTileGroups * kGroupFloats;            // 36864
-static constexpr int kTileFloats = kSmallOff + 32 * kSmallW;            // 37888 floats = 151,552 bytes per tile
+static constexpr int kTileGroups = 8 * kGroups128 + 2 * kGroups64;      // 288 groups per image
+static constexpr int kImgGroup = 16 * 4;                                // floats per group
+static constexpr int kImgZ = kTileGroups * kImgGroup;                   // z block   [16 samples][32] (columns >= n are zero)
+static constexpr int kImgG = kImgZ + 16 * 32;                           // gzb block [16 samples][32] (columns >= n are zero)
+static constexpr int kImgR = kImgG + 16 * 32;                           // r [16 samples]
+static constexpr int kImgDiag = kImgR + 16;                             // dV/dx [16][HJBX_MAX_N] as this kernel computed it (diagnostic only)
+static constexpr int kImgFloats = 20480;                                // 81,920 bytes = 80 LDS-DMA pieces
+static_assert(kImgDiag + 16 * HJBX_MAX_N <= kImgFloats, "image layout");
+static constexpr int kTileFloats = 2 * kImgFloats;                      // 163,840 bytes per tile
 __host__ __device__ constexpr int group0(int a) { return a < 8 ? a * kGroups128 : 8 * kGroups128 + (a - 8) * kGroups64; }
 
-template <int NB> __device__ __forceinline__ void store_tile_array(float* __restrict__ tile, int a, const f32x16 (&v)[NB], int e, int hh) {
-    float* base = tile + group0(a) * kGroupFloats;
+// byte offsets of this lane's four float4 slots (q = 0..3) inside a 128-byte-aligned group block: computed once per kernel, so a store
+// is wave-uniform base (SGPRs) + constant + one of four 32-bit lane offsets -- no 64-bit per-lane address arithmetic per store
+struct LaneSlots { uint32_t off[4]; };
+__device__ __forceinline__ LaneSlots lane_slots(int e, int hh) {
+    LaneSlots l;
 #pragma unroll
-    for (int fb = 0; fb < NB; ++fb)
+    for (int q = 0; q < 4; ++q)
+        l.off[q] = (uint32_t)(((e >> 4) * kImgFloats + (q * 2 + hh) * kImgGroup + (((e & 15) ^ (2 * q + hh)) * 4)) * sizeof(float));
+    return l;
+}
+template <int NB> __device__ __forceinline__ void store_tile_array(float* __restrict__ tile, int a, const f32x16 (&v)[NB], const LaneSlots& ls) {
+#pragma unroll
+    for (int fb = 0; fb < NB; ++fb) {
+        uint32_t boff = (uint32_t)((group0(a) + fb * 8) * kImgGroup * sizeof(float));
+        asm volatile("" : "+s"(boff));   // keep base + offset next to its stores: formed ahead for all 36 blocks it took 80 SGPRs (spilled)
+        char* blk = reinterpret_cast<char*>(tile) + boff;                               // wave uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(base + (((fb * 4 + q) * 2 + hh) * 32 + e) * 4) =
-                make_float4(v[fb][4 * q], v[fb][4 * q + 1], v[fb][4 * q + 2], v[fb][4 * q + 3]);
+            *reinterpret_cast<float4*>(blk + ls.off[q]) = make_float4(v[fb][4 * q], v[fb][4 * q + 1], v[fb][4 * q + 2], v[fb][4 * q + 3]);
+    }
 }
 
 // ReLU derivative masks: the 64 features a lane half holds per 128-feature array -> 2 words (bit 16 (fb & 1) + r of word fb >> 1),
@@ -76,7 +96,13 @@ __device__ __forceinline__ void relu_mask_apply(f32x16 (&v)[4], const uint32_t (
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[fb][r] *= (float)((m[fb >> 1] >> (16 * (fb & 1) + r)) & 1u);   // v_bfe_u32 + v_cvt + v_mul
+        for (int r = 0; r < 16; ++r) {
+            // v_bfe_i32 (bit -> 0 / -1) + v_and_b32, in place: no float temporaries (a multiply by (float)bit made hipcc materialise all
+            // 64 factors first and spill; and every spill reload is an s_waitcnt vmcnt(0) that also drains this wave's pending stores)
+            const float x = v[fb][r];
+            const int keep = __builtin_amdgcn_sbfe((int)m[fb >> 1], 16 * (fb & 1) + r, 1);
+            v[fb][r] = __builtin_bit_cast(float, __builtin_bit_cast(int, x) & keep);
+        }
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -95,7 +121,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
                                                                       double* __restrict__ sums_rec, int64_t B, int64_t ntiles) {
     constexpr int N = S::N, M = S::M, ACT = HJBX_ACT_RELU;
     constexpr int NP = MlpLds<N>::NP;
-    static_assert(N % 2 == 0 && 3 * N + 1 <= kSmallW, "state dimension");
+    static_assert(N % 2 == 0 && N <= 32, "state dimension");
     __shared__ __attribute__((aligned(16))) MlpLds<N> L;
     __shared__ __attribute__((aligned(16))) unsigned char sys_raw[sizeof(S)];
     S& sys_s = *reinterpret_cast<S*>(sys_raw);
@@ -111,23 +137,34 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
     const MlpP<N>& p = p_s;
     const TaskP<float, N, M>& tk = tk_s;
     const Limits<float, M>& lim = lim_s;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: tile pointers stay wave uniform (saddr stores)
     const MlpCtx c = mlp_ctx<N>(L, lane);
     const int i = c.i, h = c.h;
     double acc_h = 0, acc_t = 0, acc_ni = 0, acc_nd = 0;
+    const LaneSlots ls = lane_slots(i, h);
     // tiles are dealt wave-major over the workgroups (tile = (wave + WAVES k) gridDim + block): a small batch spreads one wave per CU
-    for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)WAVES * gridDim.x) {
-        asm volatile("" ::: "memory");   // the weights are loop invariant: keep their LDS reads inside the loop (see hjbx_mlp.hip)
+    // inputs of a tile are fetched while the previous tile is in flight (after its residual): vmcnt retires in order, so a load issued
+    // behind a tile's ~160 stores could only be waited for by draining them all
+    auto fetch = [&](int64_t tile, float (&xv)[N], float& dnv, float& cstv) __attribute__((always_inline)) {
         const int64_t env = tile * 32 + i;
-        const bool valid = env < B;
-        float xs[N];
-        if (valid) load_row<N>(x, env, xs);
+        const bool ok = tile < ntiles && env < B;
+        if (ok) load_row<N>(x, env, xv);
         else {
 #pragma unroll
-            for (int k = 0; k < N; ++k) xs[k] = p.xf[k];
+            for (int k = 0; k < N; ++k) xv[k] = p.xf[k];
         }
-        const float dn = valid ? done[env] : 0.f;
-        const float cst = valid ? cost[env] : 1.f;
+        dnv = ok ? done[env] : 0.f;
+        cstv = ok ? cost[env] : 1.f;
+    };
+    float xs_n[N], dn_n, cst_n;
+    fetch((int64_t)wave * gridDim.x + blockIdx.x, xs_n, dn_n, cst_n);
+    for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)WAVES * gridDim.x) {
+        asm volatile("" ::: "memory");   // the weights are loop invariant: keep their LDS reads inside the loop (see hjbx_mlp.hip)
+        const bool valid = tile * 32 + i < B;
+        float xs[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) xs[k] = xs_n[k];
+        const float dn = dn_n, cst = cst_n;
         float* tb = scratch + tile * (int64_t)kTileFloats;
         float e[N], z[N], ee = 0.f;
 #pragma unroll
@@ -151,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
 #pragma unroll
             for (int r = 0; r < 16; ++r) a1[0][fb][r] = act1<ACT>(a1[0][fb][r]);
         relu_mask_build(a1[0], m1);
-        store_tile_array<4>(tb, A_H1, a1[0], i, h);
+        store_tile_array<4>(tb, A_H1, a1[0], ls);
         f32x16 a2[1][4];
         zero_acc(a2);
         mfma_chain<OffW2F, 64, 4, 2, 1>(a2, ring4, c.w2f, [&](int st, int) { return a1[0][st >> 4][st & 15]; });
@@ -160,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[0][fb][r] = act1<ACT>(a2[0][fb][r]);
         relu_mask_build(a2[0], m2);
-        store_tile_array<4>(tb, A_H2, a2[0], i, h);
+        store_tile_array<4>(tb, A_H2, a2[0], ls);
         f32x16 y[1][2];
         zero_acc(y);
         mfma_chain<OffW3F, 64, 2, 2, 1>(y, ring2, c.w3f, [&](int st, int) { return a2[0][st >> 4][st & 15]; });
@@ -173,19 +210,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
                 y[0][ob][r] += y[0][ob][r];   // dy = 2y
             }
         const float V = vpart + __shfl_xor(vpart, 32, 64) + p.eps_s * ee;
-        store_tile_array<2>(tb, A_DY, y[0], i, h);
+        store_tile_array<2>(tb, A_DY, y[0], ls);
 
         // ---- input gradient ------------------------------------------------------------------------------------------
         f32x16 d2[1][4];
         zero_acc(d2);
         mfma_chain<OffW3B, 32, 4, 2, 1>(d2, ring4, c.w3b, [&](int st, int) { return y[0][st >> 4][st & 15]; });
         relu_mask_apply(d2[0], m2);
-        store_tile_array<4>(tb, A_D2, d2[0], i, h);
+        store_tile_array<4>(tb, A_D2, d2[0], ls);
         f32x16 d1[1][4];
         zero_acc(d1);
         mfma_chain<OffW2B, 64, 4, 2, 1>(d1, ring4, c.w2b, [&](int st, int) { return d2[0][st >> 4][st & 15]; });
         relu_mask_apply(d1[0], m1);
-        store_tile_array<4>(tb, A_D1, d1[0], i, h);
+        store_tile_array<4>(tb, A_D1, d1[0], ls);
         float g[N];
         {
             f32x2 part[NP / 2];
@@ -222,21 +259,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
             for (int k = 0; k < N; ++k) q[k] = 0.f;
         }
         if (h == 0 && valid) { acc_h += (double)li; acc_t += (double)lt; acc_ni += 1.0 - (double)dn; acc_nd += (double)dn; }
+        fetch(tile + (int64_t)WAVES * gridDim.x, xs_n, dn_n, cst_n);
         float gzb[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) gzb[k] = q[k] * p.istd[k];
-        if (h == 0) {
-            float rec[kSmallW];
+        if (h == 0) {   // per-sample operands of dW1 (zero-padded to 32 columns: unconditional operand reads in k_train_outer) and r
+            float* img = tb + (i >> 4) * kImgFloats;
+            const int el = i & 15;
+            float4* zp = reinterpret_cast<float4*>(img + kImgZ + el * 32);
+            float4* gp = reinterpret_cast<float4*>(img + kImgG + el * 32);
+            auto at = [&](const float (&v)[N], int k) { return k < N ? v[k < N ? k : 0] : 0.f; };
 #pragma unroll
-            for (int k = 0; k < kSmallW; ++k) rec[k] = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                zp[k] = make_float4(at(z, 4 * k), at(z, 4 * k + 1), at(z, 4 * k + 2), at(z, 4 * k + 3));
+                gp[k] = make_float4(at(gzb, 4 * k), at(gzb, 4 * k + 1), at(gzb, 4 * k + 2), at(gzb, 4 * k + 3));
+            }
+            img[kImgR + el] = r;
 #pragma unroll
-            for (int k = 0; k < N; ++k) { rec[k] = z[k]; rec[N + k] = gzb[k]; }
-            rec[2 * N] = r;
-#pragma unroll
-            for (int k = 0; k < N; ++k) rec[2 * N + 1 + k] = g[k];   // (diagnostic only: dV/dx as this kernel computed it; k_train_outer ignores it)
-            float4* sp = reinterpret_cast<float4*>(tb + kSmallOff + i * kSmallW);
-#pragma unroll
-            for (int k = 0; k < kSmallW / 4; ++k) sp[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+            for (int k = 0; k < N; ++k) img[kImgDiag + el * HJBX_MAX_N + k] = g[k];
         }
 
         // ---- reverse sweep of the input gradient with the cotangent q --------------------------------------------------------
@@ -244,12 +284,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
         zero_acc(t1);
         mfma_chain<OffW1F, N / 2, 4, 2, 1>(t1, ring4, c.w1f, [&](int st, int) { return h ? gzb[2 * st + 1] : gzb[2 * st]; });
         relu_mask_apply(t1[0], m1);
-        store_tile_array<4>(tb, A_DH1B, t1[0], i, h);
+        store_tile_array<4>(tb, A_DH1B, t1[0], ls);
         f32x16 t2[1][4];
         zero_acc(t2);
         mfma_chain<OffW2F, 64, 4, 2, 1>(t2, ring4, c.w2f, [&](int st, int) { return t1[0][st >> 4][st & 15]; });
         relu_mask_apply(t2[0], m2);
-        store_tile_array<4>(tb, A_DH2B, t2[0], i, h);
+        store_tile_array<4>(tb, A_DH2B, t2[0], ls);
         f32x16 t3[1][2];
         zero_acc(t3);
         mfma_chain<OffW3F, 64, 2, 2, 1>(t3, ring2, c.w3f, [&](int st, int) { return t2[0][st >> 4][st & 15]; });
@@ -257,17 +297,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) t3[0][ob][rr] += t3[0][ob][rr];   // yb = 2 W3' dh2b
-        store_tile_array<2>(tb, A_YB, t3[0], i, h);
+        store_tile_array<2>(tb, A_YB, t3[0], ls);
         f32x16 t4[1][4];
         zero_acc(t4);
         mfma_chain<OffW3B, 32, 4, 2, 1>(t4, ring4, c.w3b, [&](int st, int) { return t3[0][st >> 4][st & 15]; });
         relu_mask_apply(t4[0], m2);
-        store_tile_array<4>(tb, A_A2B, t4[0], i, h);
+        store_tile_array<4>(tb, A_A2B, t4[0], ls);
         f32x16 t5[1][4];
         zero_acc(t5);
         mfma_chain<OffW2B, 64, 4, 2, 1>(t5, ring4, c.w2b, [&](int st, int) { return t4[0][st >> 4][st & 15]; });
         relu_mask_apply(t5[0], m1);
-        store_tile_array<4>(tb, A_A1B, t5[0], i, h);
+        store_tile_array<4>(tb, A_A1B, t5[0], ls);
     }
     // loss sums and counts of this workgroup: lanes -> wave (shuffle tree) -> LDS -> one record (fixed order: deterministic)
     acc_h = wave_sum_d(acc_h); acc_t = wave_sum_d(acc_t); acc_ni = wave_sum_d(acc_ni); acc_nd = wave_sum_d(acc_nd);
@@ -282,40 +322,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
 }
 
 // ---- kernel 2: the outer products, summed over the samples ------------------------------------------------------------------
-// LDS image of a half tile (16 samples): every group [16 samples][4 features] padded to kGS floats so that the operand read of lane
-// (i, k) -- group i >> 2, feature i & 3, sample 2 s + k -- hits 32 distinct banks per lane half; then the small records.
-static constexpr int kGS = 16 * 4 + 4;
-static constexpr int kHalfFloats = kTileGroups * kGS + 16 * kSmallW;   // 20096 floats = 80,384 bytes; two buffers = 160,768 bytes
 static constexpr int kBlocksPerSet = 4 + 16 + 8;                       // W1: 4 column blocks; W2: 4 x 4; W3: 4 x 2
 static constexpr int kBlocks = 2 * kBlocksPerSet;
 
 template <int N>
 __global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict__ scratch, float* __restrict__ partial, int64_t ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // two images (the ONLY LDS object of this kernel: guide 5, trap 4a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    constexpr int NLD = (kTileGroups * 16 + 511) / 512;   // float4 loads per thread and half tile (groups), + 1 for the small records
-    float4 stage[NLD + 1];
-    auto issue = [&](int64_t tile, int hf) __attribute__((always_inline)) {
-        const float* tb = scratch + tile * (int64_t)kTileFloats;
+    // LDS-DMA of one image: piece p (1 KiB) by wave p % 8; the destination is wave-uniform base + lane x 16 bytes
+    auto dma = [&](int64_t tile, int hf, float* buf) __attribute__((always_inline)) {
+        const float* src = scratch + tile * (int64_t)kTileFloats + hf * kImgFloats;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int f = tid + 512 * k;
-            if (f < kTileGroups * 16) stage[k] = *reinterpret_cast<const float4*>(tb + (f >> 4) * kGroupFloats + hf * 64 + (f & 15) * 4);
+        for (int k = 0; k < kImgFloats / 256 / 8; ++k) {
+            const int p = wave + 8 * k;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
         }
-        if (tid < 16 * kSmallW / 4) stage[NLD] = *reinterpret_cast<const float4*>(tb + kSmallOff + hf * 16 * kSmallW + tid * 4);
     };
-    auto commit = [&](float* buf) __attribute__((always_inline)) {
+    // operand of lane (i, kh) at k-step s: group x = i >> 2 of its 8-group block, feature c = i & 3, sample slot (2 s + kh) ^ x
+    int lo[8];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int f = tid + 512 * k;
-            if (f < kTileGroups * 16) *reinterpret_cast<float4*>(buf + (f >> 4) * kGS + (f & 15) * 4) = stage[k];
-        }
-        if (tid < 16 * kSmallW / 4) *reinterpret_cast<float4*>(buf + kTileGroups * kGS + tid * 4) = stage[NLD];
-    };
-    // operand of lane (i, kh) for block row/column `fb` of array `a` at k-step s of a half tile
-    const int lane_off = (i >> 2) * kGS + kh * 4 + (i & 3);
-    auto opnd = [&](const float* buf, int a, int fb, int s) { return buf[(group0(a) + fb * 8) * kGS + lane_off + s * 8]; };
+    for (int s = 0; s < 8; ++s) lo[s] = (i >> 2) * kImgGroup + (((2 * s + kh) ^ (i >> 2)) * 4) + (i & 3);
+    auto opnd = [&](const float* buf, int a, int fb, int s) __attribute__((always_inline)) { return buf[(group0(a) + fb * 8) * kImgGroup + lo[s]]; };
 
     f32x16 acc[8];
 #pragma unroll
@@ -324,23 +353,20 @@ __global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict_
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     const int64_t nmine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int64_t nhalf = 2 * nmine;
-    if (nhalf > 0) {
-        issue(blockIdx.x, 0);
-        commit(lds);
-    }
+    if (nhalf > 0) dma(blockIdx.x, 0, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int64_t ht = 0; ht < nhalf; ++ht) {
-        const float* buf = lds + (ht & 1) * kHalfFloats;
-        const bool more = ht + 1 < nhalf;
-        if (more) issue(blockIdx.x + ((ht + 1) >> 1) * gridDim.x, (int)((ht + 1) & 1));
-        const float* small = buf + kTileGroups * kGS;
+        const float* buf = lds + (ht & 1) * kImgFloats;
+        // the next image streams into the other buffer while this one is consumed (every wave passed the barrier that ended that buffer's use)
+        if (ht + 1 < nhalf) dma(blockIdx.x + ((ht + 1) >> 1) * gridDim.x, (int)((ht + 1) & 1), lds + ((ht + 1) & 1) * kImgFloats);
         if (wave < 4) {
             // waves 0-3: row block ib = wave of dW2 -- acc[0..3] hjb set, acc[4..7] termination set
             const int ib = wave;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float aD = opnd(buf, A_DH1B, ib, s), aH = opnd(buf, A_H1, ib, s);
-                const float rr = small[(2 * s + kh) * kSmallW + 2 * N];
+                const float rr = buf[kImgR + 2 * s + kh];
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
                     const float bD = opnd(buf, A_D2, jb, s), bA = opnd(buf, A_A2B, jb, s);
@@ -351,16 +377,13 @@ __global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict_
             }
         } else {
             // waves 4-7: row block ib = wave - 4 of dW3 (acc[0..1] hjb, acc[2..3] termination) and column block jb = wave - 4 of dW1
-            // (acc[4] hjb, acc[5] termination; only the first N rows of that block are meaningful)
+            // (acc[4] hjb, acc[5] termination; rows >= N of those blocks multiply zero operands)
             const int ib = wave - 4;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const float aD = opnd(buf, A_DH2B, ib, s), aH = opnd(buf, A_H2, ib, s);
-                const float* rec = small + (2 * s + kh) * kSmallW;
-                const float rr = rec[2 * N];
-                const int ci = i < N ? i : 0;                       // rows >= N of the dW1 blocks are padding: zero operands
-                const float az = i < N ? rec[ci] : 0.f;
-                const float ag = i < N ? rec[N + ci] : 0.f;
+                const float rr = buf[kImgR + 2 * s + kh];
+                const float az = buf[kImgZ + (2 * s + kh) * 32 + i], ag = buf[kImgG + (2 * s + kh) * 32 + i];
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
                     const float bD = opnd(buf, A_DY, jb, s), bY = opnd(buf, A_YB, jb, s);
@@ -374,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict_
                 acc[5] = MFMA(az, rr * b1, acc[5]);
             }
         }
-        if (more) commit(lds + ((ht + 1) & 1) * kHalfFloats);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next image have landed
         __syncthreads();
     }
     // partial sums of this workgroup, raw accumulator layout [block][register][lane]
@@ -453,7 +476,7 @@ template <typename S>
 static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
                         const float* done, float* flat, void* workspace, int64_t B, void* st) {
     constexpr int N = S::N, M = S::M;
-    if constexpr (N % 2 != 0 || 3 * N + 1 > kSmallW) {
+    if constexpr (N % 2 != 0 || N > 32) {
         return HJBX_EUNSUPPORTED;
     } else {
         MlpP<N> p;
@@ -476,8 +499,8 @@ static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, c
         else
             hipLaunchKernelGGL((k_train_chains<1, S, kTrWaves>), dim3(gridA), dim3(kTrWaves * 64), 0, s, sys, p, tk, lim, W1, W2, W3, x, cost, done,
                                (float)task->eps, scratch, sums, B, w.ntiles);
-        static bool attr_set = false;   // 160,768 bytes of dynamic LDS need the opt-in once per kernel
-        const size_t lds_bytes = 2 * (size_t)kHalfFloats * sizeof(float);
+        static bool attr_set = false;   // 160 KiB of dynamic LDS need the opt-in once per kernel
+        const size_t lds_bytes = 2 * (size_t)kImgFloats * sizeof(float);
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)k_train_outer<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
                 return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: cannot reserve %zu bytes of LDS", lds_bytes);

@@ -290,3 +290,13 @@ def test_bench_self_launches_n_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_oracle_passes_address_and_ub_sanitizers():
+    """SURVEY section 5 (race / memory checking): the restatement the GPU kernels are judged against is itself run under
+    AddressSanitizer + UBSan (`make -C oracle asan`: every batch entry point, both precisions, all five systems, ragged batch,
+    exactly-sized heap buffers).  The GPU pool cannot run sanitizers, so this is the CPU-side check."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "oracle sanitizer run: ok" in r.stdout

@@ -135,17 +135,17 @@ def main():
             costs = np.array([cost(dyn, K, xf, uf, Q, R, x, 10, True, far) for x in x0])
             found = (skip, x0, costs)
             break
-    note["drone_hovering.ipynb cell 16"] = dict(printed_first=want1, printed_mean=wantm, ok=found is not None and abs(found[2].mean() - wantm) < 1e-9,
+    note["drone_hovering.ipynb cell 16"] = dict(printed_first=want1, printed_mean=wantm, ok=bool(found is not None and abs(found[2].mean() - wantm) < 1e-9),
                                                 prior_get_initial_state_calls=None if found is None else found[0],
                                                 reproduced_mean=None if found is None else float(found[2].mean()))
     if found and abs(found[2].mean() - wantm) < 1e-9:
         arrays.update(quad2d_x0=found[1], quad2d_K=K, quad2d_cost=found[2], quad2d_T=np.array([10.0]))
 
-    print(json.dumps(note, indent=1))
+    print(json.dumps(note, indent=1, default=str))
     if arrays:
         np.savez(os.path.join(out, "notebook_lqr.npz"), **arrays)
     with open(os.path.join(out, "notebook_lqr.json"), "w") as f:
-        json.dump(note, f, indent=1)
+        json.dump(note, f, indent=1, default=str)
 
 
 if __name__ == "__main__":
