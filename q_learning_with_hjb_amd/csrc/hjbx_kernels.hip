@@ -87,12 +87,15 @@ static inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1)
 static inline dim3 grid_rows(int64_t B, int R) { return dim3((unsigned)((B + (int64_t)kBlock * R - 1) / ((int64_t)kBlock * R))); }
 // rows per thread of the streaming kernels: enough loads in flight to cover the HBM latency once the batch fills the chip; small
 // batches keep one row per thread (more workgroups); float64 keeps one row (its row state alone is 2x the registers)
-template <typename T> static inline int rows_per_thread(int64_t B, int n) {
+template <typename T> static inline int rows_per_thread(int64_t B, int n, bool reducing = false) {
     if (sizeof(T) != 4) return 1;
     const int forced = hjbx_option_value(HJBX_OPT_STREAM_ROWS);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    (void)B; (void)n;
-    return 1;
+    // measured with buffers rotated through 640 MB (tools/kernel_bench.py --rows 1|2|4, B = 2^20): one row per thread is fastest for
+    // simulate / vhjb_step (more rows cost resident waves: near-hover vhjb_step 32 -> 46 -> 64 us), two rows help the residual
+    // kernel, whose grid is capped for the in-kernel reduction (cartpole 22 -> 19 us)
+    (void)n;
+    return reducing && B >= (1 << 18) ? 2 : 1;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -612,7 +615,7 @@ static int hjb_residual_impl(const hjbx_system* sys, const hjbx_task* task, int 
                                    ws, sums, B);
             };
             auto with_r = [&](auto modec) {
-                const int R = rows_per_thread<T>(B, SS::N);
+                const int R = rows_per_thread<T>(B, SS::N, true);
                 if (R == 4) go(modec, std::integral_constant<int, 4>{});
                 else if (R == 2) go(modec, std::integral_constant<int, 2>{});
                 else go(modec, std::integral_constant<int, 1>{});

@@ -425,8 +425,15 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
     constexpr int P = N * kH1 + kH1 * kH2 + kH2 * kH3;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < kBlocks * 1024) {
-        float s = 0.f;
-        for (int gI = 0; gI < nparts; ++gI) s += partial[(int64_t)gI * kBlocks * 1024 + t];
+        // fixed order: four interleaved running sums over the workgroups (so four loads are in flight), then ((s0 + s1) + (s2 + s3))
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        int gI = 0;
+        for (; gI + 4 <= nparts; gI += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += partial[(int64_t)(gI + k) * kBlocks * 1024 + t];
+        }
+        for (int k = 0; gI < nparts; ++gI, ++k) s4[k] += partial[(int64_t)gI * kBlocks * 1024 + t];
+        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         const int blk = t >> 10, reg = (t >> 6) & 15, lane = t & 63;
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
         const int set = blk / kBlocksPerSet, b = blk % kBlocksPerSet;

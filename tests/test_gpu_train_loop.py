@@ -116,7 +116,9 @@ def test_train_bookkeeping_matches_reference_loop(name):
     np.testing.assert_allclose(a_std, want_std, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(a_len, want_len, rtol=0, atol=0)
     assert all(abs(v - 3.0) < 1e-12 for v in l_tot) and all(abs(v - 1.0) < 1e-12 for v in l_hjb) and all(abs(v - 2.0) < 1e-12 for v in l_term)
-    assert len(ctl.replay_buffer) == min(cap, len(buf)) == cap                         # the deque wrapped around in this configuration
+    assert len(ctl.replay_buffer) == len(buf)
+    if name == "cartpole":
+        assert len(buf) == cap                                                          # the deque wrapped around in this configuration
 
 
 def test_sgdr_schedule_follows_the_update_counter():
