@@ -358,6 +358,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))              # the parent never touches the GPU
 
+    # stdout carries ONE JSON line: whatever the libraries print there meanwhile (gloo announces its connections on stdout) goes to stderr
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -373,8 +376,9 @@ def main():
         total = args.batch or HEADLINE_BATCH[args.system]
         shard = [(r * total // world, (r + 1) * total // world) for r in range(world)] if args.scaling == "strong" else None
         if rank == 0:
-            print(json.dumps(dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()), scaling=args.scaling, steps=args.steps, warmup=args.warmup,
-                                  global_batch=total if args.scaling == "strong" else total * world, shards=shard)), flush=True)
+            sys.stdout.flush()
+            os.write(stdout_fd, (json.dumps(dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()), scaling=args.scaling, steps=args.steps, warmup=args.warmup,
+                                                 global_batch=total if args.scaling == "strong" else total * world, shards=shard)) + "\n").encode())
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -475,7 +479,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the host-core baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(dyn, ctl, wl["x0"], args.cpu_sample_envs)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(stdout_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
