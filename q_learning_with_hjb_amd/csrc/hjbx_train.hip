@@ -81,15 +81,18 @@ template <int NB> __device__ __forceinline__ void store_tile_array(float* __rest
 // ReLU derivative masks: the 64 features a lane half holds per 128-feature array -> 2 words (bit 16 (fb & 1) + r of word fb >> 1),
 // taken from the activations (h >= +0, so h > 0 <=> its bits are non-zero).  Two registers per layer instead of keeping the 64
 // activation registers alive through the whole reverse sweep (the first version of this kernel did, and spilled 120 registers).
+// Both helpers are two-instruction inline asm on purpose.  Written in C++, hipcc recognised the AND with a sign-extended bit as a
+// select, turned every mask bit into a v_cmp whose 64-bit lane mask it kept in an SGPR pair for all three uses, and spilled the
+// resulting 256 SGPRs to VGPR lanes: ~700 v_readlane / v_writelane / v_cndmask per tile (profiles: chains at 69 % of their MFMA time).
 __device__ __forceinline__ void relu_mask_build(const f32x16 (&hv)[4], uint32_t (&m)[2]) {
     m[0] = m[1] = 0u;
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float hf = hv[fb][r];   // (bit_cast applied directly to a vector ELEMENT expression miscompiles: clang 19 / ROCm 7.2)
-            const uint32_t nz = __builtin_bit_cast(uint32_t, hf);
-            m[fb >> 1] |= (nz < 1u ? nz : 1u) << (16 * (fb & 1) + r);   // v_min_u32 + v_lshl_or_b32, no VCC
+            const float hf = hv[fb][r];   // (never bit_cast a vector ELEMENT expression directly: clang 19 miscompiles it)
+            uint32_t t;
+            asm("v_min_u32_e32 %0, 1, %2\n\tv_lshl_or_b32 %1, %0, %3, %1" : "=&v"(t), "+v"(m[fb >> 1]) : "v"(hf), "n"(16 * (fb & 1) + r));
         }
 }
 __device__ __forceinline__ void relu_mask_apply(f32x16 (&v)[4], const uint32_t (&m)[2]) {
@@ -97,11 +100,10 @@ __device__ __forceinline__ void relu_mask_apply(f32x16 (&v)[4], const uint32_t (
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            // v_bfe_i32 (bit -> 0 / -1) + v_and_b32, in place: no float temporaries (a multiply by (float)bit made hipcc materialise all
-            // 64 factors first and spill; and every spill reload is an s_waitcnt vmcnt(0) that also drains this wave's pending stores)
             const float x = v[fb][r];
-            const int keep = __builtin_amdgcn_sbfe((int)m[fb >> 1], 16 * (fb & 1) + r, 1);
-            v[fb][r] = __builtin_bit_cast(float, __builtin_bit_cast(int, x) & keep);
+            float y;   // v_bfe_i32: bit -> 0 / -1; v_and_b32 in place: no temporaries, no condition codes
+            asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32_e32 %0, %0, %3" : "=&v"(y) : "v"(m[fb >> 1]), "n"(16 * (fb & 1) + r), "v"(x));
+            v[fb][r] = y;
         }
 }
 
@@ -164,7 +166,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
         float xs[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) xs[k] = xs_n[k];
-        const float dn = dn_n, cst = cst_n;
+        float dn = dn_n, cst = cst_n;
+        asm volatile("" : "+v"(dn), "+v"(cst));   // wait for them HERE (only the previous tile's oldest stores are drained), not at their first
+                                                       // use after ~70 more stores of this tile: vmcnt retires in order
         float* tb = scratch + tile * (int64_t)kTileFloats;
         float e[N], z[N], ee = 0.f;
 #pragma unroll
@@ -340,11 +344,16 @@ __global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict_
                                              (__attribute__((address_space(3))) void*)(buf + p * 256), 16, 0, 0);
         }
     };
-    // operand of lane (i, kh) at k-step s: group x = i >> 2 of its 8-group block, feature c = i & 3, sample slot (2 s + kh) ^ x
+    // operand of lane (i, kh) at k-step s: group x = i >> 2 of its 8-group block, feature c = i & 3, sample slot (2 s + kh) ^ x.
+    // lo[s] is that lane offset; per half tile it is rebased once onto the image (B operands), onto this wave's row block (A operands)
+    // and onto the part of the image beyond the 64-KiB reach of a ds_read offset field, so that every operand read below is
+    // `ds_read_b32 v, vaddr offset:constant` with no address arithmetic of its own.
     int lo[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) lo[s] = (i >> 2) * kImgGroup + (((2 * s + kh) ^ (i >> 2)) * 4) + (i & 3);
-    auto opnd = [&](const float* buf, int a, int fb, int s) __attribute__((always_inline)) { return buf[(group0(a) + fb * 8) * kImgGroup + lo[s]]; };
+    constexpr int kFar = group0(A_DY) * kImgGroup;                       // first float beyond 64 KiB: the dy / yb arrays and the small blocks
+    static_assert(kFar * sizeof(float) == 65536 && (kImgFloats - kFar) * sizeof(float) < 65536, "ds_read offset reach");
+    const int rowblk = (wave & 3) * 8 * kImgGroup;                       // this wave's row block ib = wave & 3 of dW2 / dW3
 
     f32x16 acc[8];
 #pragma unroll
@@ -361,40 +370,78 @@ __global__ __launch_bounds__(512, 2) void k_train_outer(const float* __restrict_
         // the next image streams into the other buffer while this one is consumed (every wave passed the barrier that ended that buffer's use)
         if (ht + 1 < nhalf) dma(blockIdx.x + ((ht + 1) >> 1) * gridDim.x, (int)((ht + 1) & 1), lds + ((ht + 1) & 1) * kImgFloats);
         if (wave < 4) {
-            // waves 0-3: row block ib = wave of dW2 -- acc[0..3] hjb set, acc[4..7] termination set
-            const int ib = wave;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float aD = opnd(buf, A_DH1B, ib, s), aH = opnd(buf, A_H1, ib, s);
-                const float rr = buf[kImgR + 2 * s + kh];
+            // waves 0-3: row block ib = wave of dW2 -- acc[0..3] hjb set, acc[4..7] termination set.  Operands of k-step s + 1 are read
+            // while the 12 MFMAs of k-step s issue (two register sets, pinned by sched_barrier).
+            struct Ops { float aD, aH, rr, bD[4], bA[4]; };
+            auto load = [&](int s) __attribute__((always_inline)) {
+                Ops o;
+                const float* pa = buf + rowblk + lo[s];
+                const float* pb = buf + lo[s];
+                o.aD = pa[group0(A_DH1B) * kImgGroup];
+                o.aH = pa[group0(A_H1) * kImgGroup];
+                o.rr = (buf + kFar)[kImgR - kFar + 2 * s + kh];
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
-                    const float bD = opnd(buf, A_D2, jb, s), bA = opnd(buf, A_A2B, jb, s);
-                    acc[jb] = MFMA(aD, bD, acc[jb]);
-                    acc[jb] = MFMA(aH, bA, acc[jb]);
-                    acc[4 + jb] = MFMA(aH, rr * bD, acc[4 + jb]);
+                    o.bD[jb] = pb[(group0(A_D2) + jb * 8) * kImgGroup];
+                    o.bA[jb] = pb[(group0(A_A2B) + jb * 8) * kImgGroup];
                 }
+                return o;
+            };
+            Ops cur = load(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                Ops nxt = cur;
+                if (s + 1 < 8) nxt = load(s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    acc[jb] = MFMA(cur.aD, cur.bD[jb], acc[jb]);
+                    acc[jb] = MFMA(cur.aH, cur.bA[jb], acc[jb]);
+                    acc[4 + jb] = MFMA(cur.aH, cur.rr * cur.bD[jb], acc[4 + jb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
         } else {
             // waves 4-7: row block ib = wave - 4 of dW3 (acc[0..1] hjb, acc[2..3] termination) and column block jb = wave - 4 of dW1
             // (acc[4] hjb, acc[5] termination; rows >= N of those blocks multiply zero operands)
-            const int ib = wave - 4;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float aD = opnd(buf, A_DH2B, ib, s), aH = opnd(buf, A_H2, ib, s);
-                const float rr = buf[kImgR + 2 * s + kh];
-                const float az = buf[kImgZ + (2 * s + kh) * 32 + i], ag = buf[kImgG + (2 * s + kh) * 32 + i];
+            struct Ops { float aD, aH, rr, az, ag, bD[2], bY[2], b1, bA1; };
+            auto load = [&](int s) __attribute__((always_inline)) {
+                Ops o;
+                const float* pa = buf + rowblk + lo[s];
+                const float* pb = buf + lo[s];
+                const float* far = buf + kFar;
+                o.aD = pa[group0(A_DH2B) * kImgGroup];
+                o.aH = pa[group0(A_H2) * kImgGroup];
+                o.rr = far[kImgR - kFar + 2 * s + kh];
+                o.az = far[kImgZ - kFar + (2 * s + kh) * 32 + i];
+                o.ag = far[kImgG - kFar + (2 * s + kh) * 32 + i];
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
-                    const float bD = opnd(buf, A_DY, jb, s), bY = opnd(buf, A_YB, jb, s);
-                    acc[jb] = MFMA(aD, bD, acc[jb]);
-                    acc[jb] = MFMA(aH, bY, acc[jb]);
-                    acc[2 + jb] = MFMA(aH, rr * bD, acc[2 + jb]);
+                    o.bD[jb] = (far + lo[s])[(group0(A_DY) + jb * 8) * kImgGroup - kFar];
+                    o.bY[jb] = (far + lo[s])[(group0(A_YB) + jb * 8) * kImgGroup - kFar];
                 }
-                const float b1 = opnd(buf, A_D1, ib, s), bA1 = opnd(buf, A_A1B, ib, s);
-                acc[4] = MFMA(ag, b1, acc[4]);
-                acc[4] = MFMA(az, bA1, acc[4]);
-                acc[5] = MFMA(az, rr * b1, acc[5]);
+                o.b1 = (pb + rowblk)[group0(A_D1) * kImgGroup];          // column block jb = wave - 4: the same 8-group offset as the row block
+                o.bA1 = (pb + rowblk)[group0(A_A1B) * kImgGroup];
+                return o;
+            };
+            Ops cur = load(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                Ops nxt = cur;
+                if (s + 1 < 8) nxt = load(s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    acc[jb] = MFMA(cur.aD, cur.bD[jb], acc[jb]);
+                    acc[jb] = MFMA(cur.aH, cur.bY[jb], acc[jb]);
+                    acc[2 + jb] = MFMA(cur.aH, cur.rr * cur.bD[jb], acc[2 + jb]);
+                }
+                acc[4] = MFMA(cur.ag, cur.b1, acc[4]);
+                acc[4] = MFMA(cur.az, cur.bA1, acc[4]);
+                acc[5] = MFMA(cur.az, cur.rr * cur.b1, acc[5]);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next image have landed
