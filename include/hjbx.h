@@ -293,6 +293,12 @@ size_t hjbx_value_loss_grad_workspace_bytes(int64_t B);
 int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
                              const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream);
 
+/* The step between that buffer (after the all-reduce, if any) and Adam: mixed[k] = flat[k] / (#interior + eps) + reg * flat[P + k] / (#done + eps)
+ * for the P = n_params parameter entries (vhjb.py:241, 253, 284) and losses[0..2] = {hjb + reg termination, hjb, termination} (vhjb.py:285-288;
+ * losses may be NULL).  reg is read from reg_dev[0] when reg_dev is non-NULL (a device scalar survives hipGraph replay), else from `reg`. */
+int hjbx_mix_gradients_f32(const float* flat, int64_t n_params, const float* reg_dev, double reg, double eps, float* mixed, float* losses,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

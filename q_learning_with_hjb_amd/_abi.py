@@ -196,7 +196,7 @@ def _typed_signatures():
 EXPORTED_SYMBOLS = (
     ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_set_option", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
      "hjbx_reduce_workspace_bytes", "hjbx_rollout_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32",
-     "hjbx_value_loss_grad_workspace_bytes", "hjbx_value_loss_grad_f32"]
+     "hjbx_value_loss_grad_workspace_bytes", "hjbx_value_loss_grad_f32", "hjbx_mix_gradients_f32"]
     + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
 )
 
@@ -236,6 +236,8 @@ def lib() -> C.CDLL:
         L.hjbx_value_loss_grad_workspace_bytes.argtypes = [_I64]
         L.hjbx_value_loss_grad_f32.restype = C.c_int
         L.hjbx_value_loss_grad_f32.argtypes = [_VP, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
+        L.hjbx_mix_gradients_f32.restype = C.c_int
+        L.hjbx_mix_gradients_f32.argtypes = [_VP, _I64, _VP, _DBL, _DBL, _VP, _VP, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")

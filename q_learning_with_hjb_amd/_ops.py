@@ -288,3 +288,17 @@ def value_loss_grad(sys, task, mlp_desc, x, cost, done, mode=_abi.RESIDUAL_NORMA
         _tws[key] = ws
     check(lib().hjbx_value_loss_grad_f32(sys.ptr, ref(task), ref(mlp_desc), int(mode), _p(x), _p(cost), _p(done), _p(flat), _p(ws), B, _stream()))
     return flat
+
+
+def mix_gradients(flat, n_params, regularization, eps):
+    """hjbx_mix_gradients_f32: -> (mixed (P,), losses (3,) = [total, hjb, termination]).  `regularization`: float or 0-dim float32 CUDA tensor."""
+    _chk(flat, "flat", (2 * n_params + 4,), torch.float32)
+    mixed = torch.empty((n_params,), dtype=torch.float32, device=flat.device)
+    losses = torch.empty((3,), dtype=torch.float32, device=flat.device)
+    if torch.is_tensor(regularization):
+        _chk(regularization, "regularization", (), torch.float32)
+        reg_dev, reg = _p(regularization), 0.0
+    else:
+        reg_dev, reg = None, float(regularization)
+    check(lib().hjbx_mix_gradients_f32(_p(flat), int(n_params), reg_dev, reg, float(eps), _p(mixed), _p(losses), _stream()))
+    return mixed, losses

@@ -232,7 +232,9 @@ class ReplayBuffer:
     def num_batches(self, batch_size: int) -> int:
         return self.size // batch_size
 
-    def batches(self, batch_size: int, generator=None, limit: Optional[int] = None):
+    def batches(self, batch_size: int, generator=None, limit: Optional[int] = None, out=None):
+        """Minibatches (xs, costs, dones) of one pass over a fresh permutation, drop-last.  `out` = (xs, costs, dones) buffers to gather
+        into (the static inputs of a captured update graph: saves three device copies per step); the same buffers are yielded each time."""
         nb = self.num_batches(batch_size)
         if limit is not None:
             nb = min(nb, limit)
@@ -241,7 +243,13 @@ class ReplayBuffer:
         perm = torch.randperm(self.size, device=self.x.device, generator=generator)
         for b in range(nb):
             idx = perm[b * batch_size:(b + 1) * batch_size]
-            yield self.x[idx], self.cost[idx], self.done[idx]
+            if out is not None:
+                torch.index_select(self.x, 0, idx, out=out[0])
+                torch.index_select(self.cost, 0, idx, out=out[1])
+                torch.index_select(self.done, 0, idx, out=out[2])
+                yield out
+            else:
+                yield self.x[idx], self.cost[idx], self.done[idx]
 
 
 class VHJBController(Controller):
@@ -541,7 +549,16 @@ class VHJBController(Controller):
                                         self.residual_mode)
             if self._distributed():
                 torch.distributed.all_reduce(flat, group=self.process_group)
-            grads, hjb_loss, termination_loss = mix_flat(flat, model_params, regularization, self.epsilon)
+            P = sum(p.numel() for p in model_params)
+            mixed, losses = _ops.mix_gradients(flat, P, regularization, self.epsilon)     # counts, mix and the three losses in one launch
+            grads, off = [], 0
+            for p in model_params:
+                grads.append(mixed[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            for p, gr in zip(model_params, grads):
+                p.grad = gr
+            self.optimizer.step()
+            return losses[0], losses[1], losses[2]
         else:
             # differentiate w.r.t. fresh leaves that alias the parameters: their grad accumulators are created on the stream this
             # step runs on, so a hipGraph capture cannot be joined to the stream of an older, still-alive autograd graph of the
@@ -572,7 +589,8 @@ class VHJBController(Controller):
         """`params_update` replayed from a hipGraph captured on first use for this minibatch shape: the same kernels in the
         same order, without ~100 host-side launches per step.  The returned losses are views of the graph's static outputs:
         consume them before the next call."""
-        xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
+        if not (self._graphed_update is not None and xs is self._graphed_update.inputs[0]):
+            xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
         if self._reg_buf is None:
             self._reg_buf = torch.zeros((), dtype=self.dtype, device=self.device)
         self._reg_buf.fill_(float(regularization))
@@ -612,7 +630,10 @@ class VHJBController(Controller):
                 nbt = torch.tensor([nb], device=self.device)
                 torch.distributed.all_reduce(nbt, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
                 nb = int(nbt.item())
-            for xs, costs, dones in self.replay_buffer.batches(per_rank_batch, generator=self._gen, limit=nb):
+            # with a captured update graph the minibatch is gathered straight into the graph's static input buffers
+            gu = self._graphed_update if self.graph_updates else None
+            static = (gu.inputs[0], gu.inputs[2], gu.inputs[1]) if gu is not None and gu.inputs[0].shape[0] == per_rank_batch else None
+            for xs, costs, dones in self.replay_buffer.batches(per_rank_batch, generator=self._gen, limit=nb, out=static):
                 update = self.params_update_graphed if self.graph_updates else self.params_update
                 total_loss, hjb_loss, termination_loss = update(xs, dones, costs, self.regularization)
                 total_losses = total_losses + total_loss
@@ -678,7 +699,8 @@ class GraphedStep:
 
     def __call__(self, *inputs):
         for buf, t in zip(self.inputs, inputs):
-            buf.copy_(t)
+            if t is not buf:                                   # (the caller may have filled the static buffer in place)
+                buf.copy_(t)
         self.graph.replay()
         return self.out
 

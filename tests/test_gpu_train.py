@@ -162,3 +162,22 @@ def test_value_loss_grad_rejects_what_it_cannot_do():
     flat = _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs[:0].contiguous(), costs[:0].contiguous(),
                                 dones[:0].contiguous())
     assert float(flat.abs().max()) == 0.0
+
+
+def test_mix_gradients_kernel_vs_formula():
+    """hjbx_mix_gradients_f32 == g_h / (#interior + eps) + reg g_t / (#done + eps) and the three losses (vhjb.py:241, 253, 284-288), with the
+    regularisation weight as a host value and as a device scalar (the hipGraph form)."""
+    from q_learning_with_hjb_amd.controller.vhjb import mix_flat
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    P = 4 * 128 + 128 * 128 + 128 * 64
+    flat = torch.randn(2 * P + 4, generator=gen, device="cuda")
+    flat[2 * P:] = torch.tensor([37.5, 12.25, 187.0, 69.0], device="cuda")
+    shapes = [torch.empty(4, 128), torch.empty(128, 128), torch.empty(128, 64)]
+    want, wh, wt = mix_flat(flat.double(), shapes, 0.37, 1e-10)
+    for reg in (0.37, torch.tensor(0.37, device="cuda")):
+        mixed, losses = _ops.mix_gradients(flat, P, reg, 1e-10)
+        got = mixed.double()
+        ref = torch.cat([w.reshape(-1) for w in want])
+        assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        assert abs(float(losses[1]) - float(wh)) < 1e-6 * abs(float(wh)) and abs(float(losses[2]) - float(wt)) < 1e-6 * abs(float(wt))
+        assert abs(float(losses[0]) - float(wh + 0.37 * wt)) < 1e-6 * abs(float(wh + 0.37 * wt))
