@@ -35,7 +35,7 @@ RTOL = 1e-5                      # BASELINE.json north_star: "trajectories match
 DELTA = 1e-3                     # (ii): margin to the observation box, in error-coordinate units
 KINK = 1e-5                      # (i): an environment is "at a kink" when some hidden pre-activation has |a| < KINK * (sum of |terms| of that unit);
                                  #      float32 accumulation of a 128-term pre-activation is good to ~1e-6 of that sum (worst case 128 x 6e-8 = 8e-6)
-FULL = {"cartpole": 1 << 20, "quad2d": 1 << 18, "nearhover": 1 << 20}   # configs[1], [3], [4]
+FULL = {"cartpole": 1 << 20, "acrobot": 1 << 20, "quad2d": 1 << 18, "nearhover": 1 << 20}   # configs[1], [2], [3], [4]
 _report = {}
 
 
@@ -101,7 +101,7 @@ def stats(err, bound):
 
 
 @pytest.mark.parametrize("weights", ["lqr", "random"])
-@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
+@pytest.mark.parametrize("name", ["cartpole", "acrobot", "quad2d", "nearhover"])
 def test_teacher_forced_single_step_per_element(name, weights):
     """(i) one closed-loop step of the fused MFMA kernel from the same float32 states, full batch, per element."""
     d, ctl, vf, mlp, W = setup(name, weights)
@@ -187,7 +187,7 @@ def _margins(s, task_cfg, traj, ai):
     return np.minimum(omax[None, None, :] - e, e - omin[None, None, :]).min(-1)
 
 
-@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
+@pytest.mark.parametrize("name", ["cartpole", "acrobot", "quad2d", "nearhover"])
 def test_done_step_bit_equal_outside_margin(name):
     """(ii) `done_step` of the fused rollout == the f64 oracle's, bit for bit, for every environment that never comes within DELTA of
     a face of the observation box while alive (an environment inside that band can legitimately cross one step apart in float32)."""
