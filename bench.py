@@ -46,6 +46,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; AMD's 5 PF figure includes 2:1 sparsity)
+ARITHMETIC = "f32"              # set from --arithmetic in main()
 HEADLINE_BATCH = {"cartpole": 1 << 20, "acrobot": 1 << 20, "quad2d": 1 << 18, "nearhover": 1 << 20, "linear": 1 << 20}
 
 
@@ -62,6 +64,9 @@ def parse():
                     help="default cartpole = BASELINE configs[1]; quad2d / nearhover = the VHJB loops of configs[3] / configs[4]")
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"], help="euler = the reference's integrator (parity mode)")
     ap.add_argument("--activation", default="relu", choices=["relu", "tanh"], help="relu = controller/vhjb.py (the BASELINE workload); tanh = the cartpole notebook's network")
+    ap.add_argument("--arithmetic", default="f32", choices=["f32", "bf16x3"],
+                    help="value-network arithmetic of the fused kernels: f32 = float32 MFMA (an fmaf chain, bitwise); bf16x3 = every float32 operand split "
+                         "exactly into three bfloat16 pieces, six piece products on the bf16 matrix cores (HJBX_OPT_MLP_ARITHMETIC)")
     ap.add_argument("--chunk", type=int, default=0, help="steps per persistent launch (0 = all K steps in one launch)")
     ap.add_argument("--prewarm", type=float, default=0.3, help="seconds of untimed clock pre-warm on scratch state before the W warm-up steps (0 for counter runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,6 +241,16 @@ def mfma_roofline(wl, launches, B):
     launch_ms = ms * steps_per_launch
     ach = wl["flops_per_env"] * B / (ms * 1e-3) / 1e12
     alg, meas = rollout_traffic_model(wl["n"], wl["m"], B, steps_per_launch)
+    if ARITHMETIC == "bf16x3":
+        # executed matrix-core work: layers 2, 3 forward and backward as six bf16 piece products each (layer 1 stays on the f32 MFMA and is
+        # not counted); priced against the dense bf16 peak
+        executed = 6 * 4.0 * (128 * 128 + 128 * 64)
+        ach16 = executed * B / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", kernel="k_vhjb_rollout_mfma<bf16x3> (hjbx_vhjb_rollout_f32, HJBX_OPT_MLP_ARITHMETIC=1)", achieved=ach16,
+                    peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach16 / MFMA_BF16_PEAK_TFLOPS, traffic=meas, traffic_algorithmic=alg,
+                    avg_launch_ms=launch_ms, steps_per_launch=steps_per_launch, flop_per_env_step=executed,
+                    note="achieved = EXECUTED bf16 MFMA flops (6 piece products per float32 product); the float32-equivalent rate is f32_equivalent",
+                    f32_equivalent=ach, f32_equivalent_over_f32_mfma_peak=ach / MFMA_F32_PEAK_TFLOPS)
     return dict(bound="mfma", kernel="k_vhjb_rollout_mfma (hjbx_vhjb_rollout_f32)", achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=meas, traffic_algorithmic=alg, avg_launch_ms=launch_ms, steps_per_launch=steps_per_launch,
                 flop_per_env_step=wl["flops_per_env"])
@@ -404,7 +419,10 @@ def main():
         pkg.build_library()                      # no-op when csrc/libhjbx.so is current (it ships prebuilt)
     if world > 1:
         dist.barrier()
-    from q_learning_with_hjb_amd import _ops
+    from q_learning_with_hjb_amd import _abi, _ops
+    global ARITHMETIC
+    ARITHMETIC = args.arithmetic
+    _abi.set_option(_abi.OPT_MLP_ARITHMETIC, 1 if args.arithmetic == "bf16x3" else 0)
 
     def barrier():
         if dist is not None:
@@ -443,7 +461,8 @@ def main():
 
     out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20" if args.system == "cartpole" else
                f"env-steps/sec (batched HJB rollouts), {args.system}", value=value, unit="env-steps/s", n_gpus=world,
-               steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f32",
+               steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+               dtype="f32" if args.arithmetic == "f32" else "f32 (value-network products as 3-way bf16 splits on the bf16 MFMA, f32 accumulation)",
                data="synthetic", reps=reps, ms_per_step_min=float(walls.min()) / K * 1e3, ms_per_step_max=float(walls.max()) / K * 1e3,
                config=dict(workload=wl["label"], batch_per_gpu=B, global_batch=global_batch,
                            state_dim=n, control_dim=m, integrator=args.integrator, mlp=f"{n}-128-128-64 {args.activation}, no bias",

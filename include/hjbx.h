@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 104 /* major*100 + minor */
+#define HJBX_VERSION 105 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -91,15 +91,20 @@ typedef enum hjbx_controller_kind {
                                           the control of each step (time-to-origin loops of the time-optimal notebook,
                                           cell 9); done_step = index of that step */
 
-/* Process-wide tuning / test knobs (hjbx_set_option).  None of them changes results. */
+/* Process-wide tuning / test knobs (hjbx_set_option).  Options 0-2 do not change results. */
 typedef enum hjbx_option {
     HJBX_OPT_ROLLOUT_SCHEDULE = 0,         /* work distribution of hjbx_vhjb_rollout_f32: 0 (default) = equal static shares per workgroup, with
                                               the shares of workgroups that have not started taken over by the waves that finish first;
                                               1 = device-wide tile queue (one atomic per 32-environment tile) */
     HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS = 1, /* TEST HOOK: launch this many workgroups more than there are CUs (they cannot be resident until
                                               others finish -- the situation the take-over above exists for); default 0 */
-    HJBX_OPT_STREAM_ROWS = 2               /* TUNING: rows per thread of the float32 streaming kernels (simulate, vhjb_step, hjb_residual):
+    HJBX_OPT_STREAM_ROWS = 2,              /* TUNING: rows per thread of the float32 streaming kernels (simulate, vhjb_step, hjb_residual):
                                               1, 2 or 4; 0 (default) = the library's choice */
+    HJBX_OPT_MLP_ARITHMETIC = 3            /* arithmetic of the ReLU value network inside hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 (THE ONE KNOB
+                                              THAT CHANGES RESULTS, within float32 rounding): 0 (default) = float32 MFMA, bitwise an fmaf chain;
+                                              1 = every float32 operand split exactly into three bfloat16 pieces, the six largest piece products
+                                              on the bf16 matrix cores with float32 accumulation (dropped products <= 2^-22 of each term; layer 1
+                                              and everything outside the network stay float32).  tanh networks ignore it. */
 } hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */

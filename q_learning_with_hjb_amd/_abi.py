@@ -24,7 +24,7 @@ LAW_QUADRATIC, LAW_BANGBANG = 0, 1
 ACT_RELU, ACT_TANH, ACT_SIN = 0, 1, 2
 ROLLOUT_TERMINATE = 1
 ROLLOUT_STOP_AT_TARGET = 2
-OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS, OPT_STREAM_ROWS = 0, 1, 2
+OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS, OPT_STREAM_ROWS, OPT_MLP_ARITHMETIC = 0, 1, 2, 3
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -33,9 +33,10 @@ _LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
 _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=0",), "hjbx_mlp_relu.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"),
+          ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=2",), "hjbx_mlp_x3.o"),
           ("hjbx_train.hip", (), "hjbx_train.o"))
 _SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
-_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", os.path.join("..", "..", "include", "hjbx.h"))
+_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", "hjbx_mlp_x3.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 
 
 class HjbxTask(C.Structure):

@@ -35,18 +35,22 @@
 #include "hjbx_systems.hpp"
 #include "hjbx_host.hpp"
 #include "hjbx_mlp_core.hpp"
+#include "hjbx_mlp_x3.hpp"
 
 using namespace hjbx;
 
 // launch shape: TL tiles of 32 environments per wave, WAVES waves per workgroup (one workgroup per CU).
 //   (TL, WAVES) = (1, 8): two waves per SIMD, 256 VGPRs each.   (2, 4): one wave per SIMD, 512 VGPRs.
-// This file is compiled once per activation (-DHJBX_MLP_ACT=0 relu, =1 tanh: 30 kernel instantiations each, side by side);
-// the relu object also carries the two C entry points, which validate and hand over to the object of the requested activation.
+// This file is compiled once per variant (-DHJBX_MLP_ACT=0 relu, =1 tanh, =2 relu with the bf16x3-split arithmetic of hjbx_mlp_x3.hpp:
+// 30 kernel instantiations each, side by side); the relu object also carries the two C entry points, which validate and hand over to
+// the object of the requested variant.
 #ifndef HJBX_MLP_ACT
-#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points) and again with -DHJBX_MLP_ACT=1 (tanh)"
+#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points), =1 (tanh) and =2 (relu, bf16x3-split MFMA)"
 #endif
-static constexpr int kAct = HJBX_MLP_ACT;
+static constexpr bool kX3 = HJBX_MLP_ACT == 2;
+static constexpr int kAct = kX3 ? HJBX_ACT_RELU : HJBX_MLP_ACT;
 static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH, "fused kernels exist for relu and tanh");
+template <int N, bool X3> using MlpLdsT = std::conditional_t<X3, MlpLdsX3<N>, MlpLds<N>>;
 #define HJBX_MLP_CAT2(a, b) a##b
 #define HJBX_MLP_CAT(a, b) HJBX_MLP_CAT2(a, b)
 #define HJBX_MLP_SYM(name) HJBX_MLP_CAT(name, HJBX_MLP_ACT)
@@ -54,6 +58,9 @@ static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH, "fused kernels exi
 // per-activation dispatchers (system kind -> kernel instantiation), one pair per object file
 HJBX_HIDDEN int hjbx_mlp_value_grad_act0(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_value_grad_act1(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_value_grad_act2(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_rollout_act2(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act0(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
                                       float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
@@ -67,23 +74,28 @@ HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, cons
 #endif
 
 // ---- kernel 1: V and dV/dx for a batch of states (hjbx_value_grad_f32) ---------------------------------------
-template <typename S, int TL, int WAVES, int ACT>
+template <typename S, int TL, int WAVES, int ACT, bool X3>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
                                                                          const float* __restrict__ W2g, const float* __restrict__ W3g,
                                                                          const float* __restrict__ x, float* __restrict__ Vout,
                                                                          float* __restrict__ gout, int64_t B, int64_t ngroups) {
     constexpr int N = S::N;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
-    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    static_assert(!X3 || TL == 1, "the bf16x3-split chain holds one tile per wave");
+    __shared__ __attribute__((aligned(256))) MlpLdsT<N, X3> L;
     const int tid = threadIdx.x;
     if (tid == 0) L.next = WAVES;  // groups 0..WAVES-1 of the range are taken statically
 #ifdef HJBX_DIAG_CLOCK
     const unsigned long long tentry = __builtin_amdgcn_s_memrealtime();
 #endif
-    mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    if constexpr (X3) mlp_fill_lds_x3<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    else mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
-    const MlpCtx c = mlp_ctx<N>(L, lane);
+    const auto c = [&] {
+        if constexpr (X3) return mlp_ctx_x3<N>(L, lane);
+        else return mlp_ctx<N>(L, lane);
+    }();
     const int i = c.i, h = c.h;
 
     // Work distribution: the workgroup owns a contiguous range of tile groups and its waves pull the next one
@@ -124,7 +136,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
         load_rows(grp_next, xn);
 
         float V[TL], g[TL][N];
-        mlp_value_grad<S, TL, ACT>(sys, p, c, xs, gout != nullptr, V, g);
+        if constexpr (X3) mlp_value_grad_x3<S>(sys, p, c, xs, gout != nullptr, V, g);
+        else mlp_value_grad<S, TL, ACT>(sys, p, c, xs, gout != nullptr, V, g);
 #pragma unroll
         for (int t = 0; t < TL; ++t) {
             const int64_t env = (grp * TL + t) * 32 + i;
@@ -178,7 +191,7 @@ static constexpr int kWsOpen = kWsFlags + kMaxGrid;     // [kMaxGrid] next uncla
 static constexpr int kWsWords = kWsOpen + kMaxGrid;
 #define HJBX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-template <int INTEG, typename S, int WAVES, int ACT>
+template <int INTEG, typename S, int WAVES, int ACT, bool X3>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
                                                                            Limits<float, S::M> lim_k, const float* __restrict__ W1g,
                                                                            const float* __restrict__ W2g, const float* __restrict__ W3g,
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
                                                                            int64_t ngroups, unsigned* ws, int sched) {
     constexpr int N = S::N, M = S::M;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
-    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    __shared__ __attribute__((aligned(256))) MlpLdsT<N, X3> L;
     // System, task, limits and normalisation constants are staged in LDS: as kernel arguments they are ~100-250 wave-uniform
     // scalars that do not fit the SGPR file next to the address arithmetic, and hipcc spilled them to VGPR lanes
     // (hundreds of v_readlane / v_writelane per step, some inside the MFMA chains).  LDS broadcast reads cost no SGPRs.
@@ -213,14 +226,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
         __hip_atomic_fetch_add(ws + kWsStarted, 1u, HJBX_RLX_AGENT);
         sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k;
     }
-    mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    if constexpr (X3) mlp_fill_lds_x3<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    else mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     __syncthreads();
     const S& sys = sys_s;
     const MlpP<N>& p = p_s;
     const TaskP<float, N, M>& tk = tk_s;
     const Limits<float, M>& lim = lim_s;
     const int lane = tid & 63, wave = tid >> 6;
-    const MlpCtx c = mlp_ctx<N>(L, lane);
+    const auto c = [&] {
+        if constexpr (X3) return mlp_ctx_x3<N>(L, lane);
+        else return mlp_ctx<N>(L, lane);
+    }();
     const int i = c.i, h = c.h;
     const int simd = wave & 3;
     const int G = (int)gridDim.x;
@@ -311,7 +328,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
                 cst = dn = res = 0.0f;
             } else {
                 float V[1], g[1][N];
-                mlp_value_grad<S, 1, ACT>(sys, p, c, xs, true, V, g);
+                if constexpr (X3) mlp_value_grad_x3<S>(sys, p, c, xs, true, V, g);
+                else mlp_value_grad<S, 1, ACT>(sys, p, c, xs, true, V, g);
                 vhjb_step_env<INTEG>(sys, tk, lim, t_first + k, T_max, o.resid != nullptr, xs[0], g[0], ds, xo, u, cst, dn, res);
             }
             if (writer) {
@@ -368,7 +386,7 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
     // one resident workgroup per CU (106 KB of LDS each); small batches are spread one tile group per CU
     // rather than packed eight to a workgroup, so up to n_cu matrix pipes work on them
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;
-    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, kAct>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
+    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, kAct, kX3>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
                        (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_grad_f32: %s", hipGetErrorString(e));
@@ -377,6 +395,10 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
 
 // system kind -> instantiation of this object's activation (arguments already validated by the C entry point)
 int HJBX_MLP_SYM(hjbx_mlp_value_grad_act)(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* stream) {
+#ifdef HJBX_MLP_DEV  // development builds: cartpole only (30 instantiations take a minute per variant)
+    if (sys->kind == HJBX_SYS_CARTPOLE) { Cartpole<float> c{}; return launch_value_grad(c, mlp, x, V, g, B, stream); }
+    return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: development build (cartpole only)");
+#else
     switch (sys->kind) {
     case HJBX_SYS_LINEAR:
         if (sys->n == 2) {
@@ -392,6 +414,7 @@ int HJBX_MLP_SYM(hjbx_mlp_value_grad_act)(const hjbx_system* sys, const hjbx_mlp
     case HJBX_SYS_NEARHOVER: { NearHover<float> q{}; return launch_value_grad(q, mlp, x, V, g, B, stream); }
     }
     return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: no kernel for system kind %d with n=%d", sys->kind, sys->n);
+#endif
 }
 
 
@@ -412,8 +435,9 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
         return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: x / gradV must be aligned to their row vector width");
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: normalization_std[%d] is zero", k);
-    return mlp->activation == HJBX_ACT_TANH ? hjbx_mlp_value_grad_act1(sys, mlp, x, V, g, B, stream)
-                                            : hjbx_mlp_value_grad_act0(sys, mlp, x, V, g, B, stream);
+    if (mlp->activation == HJBX_ACT_TANH) return hjbx_mlp_value_grad_act1(sys, mlp, x, V, g, B, stream);
+    return hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 1 ? hjbx_mlp_value_grad_act2(sys, mlp, x, V, g, B, stream)
+                                                           : hjbx_mlp_value_grad_act0(sys, mlp, x, V, g, B, stream);
 }
 #endif
 
@@ -444,7 +468,7 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     if (grid > kMaxGrid) grid = kMaxGrid;
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
     auto launch = [&](auto integ) {
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, kAct>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, kAct, kX3>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
                            (hipStream_t)st, sys, p, tk, lim, W1, W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups, (unsigned*)workspace, sched);
     };
     if (integrator == HJBX_EULER) launch(std::integral_constant<int, 0>{});
@@ -459,6 +483,23 @@ int HJBX_MLP_SYM(hjbx_mlp_rollout_act)(const hjbx_system* sys, const hjbx_task* 
                                        int T_max, const float* x, float* traj, float* u_log, float* cost, float* done, float* resid,
                                        int32_t* done_step, float* x_out, const int32_t* env_order, int64_t B, void* workspace, void* stream) {
     int rc = HJBX_EUNSUPPORTED;
+#ifdef HJBX_MLP_DEV
+    if (sys->kind == HJBX_SYS_CARTPOLE && integrator == HJBX_EULER) {
+        Cartpole<float> S{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
+        constexpr int WAVES = HJBX_MLP_WAVES;
+        MlpP<4> p;
+        for (int k = 0; k < 4; ++k) { p.mean[k] = (float)mlp->mean[k]; p.istd[k] = (float)(1.0 / mlp->std[k]); p.xf[k] = (float)mlp->xf[k]; }
+        p.eps_s = (float)mlp->eps_scalar;
+        RolloutOut<4, 1> o{traj, u_log, cost, done, resid, done_step, x_out};
+        const int64_t ngroups = (B + 31) / 32;
+        int64_t grid = ngroups < 256 ? ngroups : 256;
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, Cartpole<float>, WAVES, kAct, kX3>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)stream, S, p,
+                           make_task<float, 4, 1>(task), make_limits<float, 1>(sys), (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, t_first,
+                           n_steps, T_max, x, env_order, o, B, ngroups, (unsigned*)workspace, hjbx_option_value(HJBX_OPT_ROLLOUT_SCHEDULE));
+        return hipGetLastError() == hipSuccess ? HJBX_OK : hjbx_set_error(HJBX_EHIP, "launch");
+    }
+    return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: development build (cartpole, Euler only)");
+#else
     const bool ok = with_system<float>(sys, [&](auto S) {
         using SS = decltype(S);
         if constexpr (SS::N % 2 == 0)
@@ -468,6 +509,7 @@ int HJBX_MLP_SYM(hjbx_mlp_rollout_act)(const hjbx_system* sys, const hjbx_task* 
     if (!ok || rc == HJBX_EUNSUPPORTED)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_vhjb_rollout_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
     return rc;
+#endif
 }
 
 #if HJBX_MLP_ACT == 0
@@ -497,8 +539,10 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
         return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: x / traj / x_out / u_log must be aligned to their row vector width");
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: normalization_std[%d] is zero", k);
-    return mlp->activation == HJBX_ACT_TANH
-               ? hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream)
+    if (mlp->activation == HJBX_ACT_TANH)
+        return hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
+    return hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 1
+               ? hjbx_mlp_rollout_act2(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream)
                : hjbx_mlp_rollout_act0(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
 }
 #endif
