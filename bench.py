@@ -64,9 +64,10 @@ def parse():
                     help="default cartpole = BASELINE configs[1]; quad2d / nearhover = the VHJB loops of configs[3] / configs[4]")
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"], help="euler = the reference's integrator (parity mode)")
     ap.add_argument("--activation", default="relu", choices=["relu", "tanh"], help="relu = controller/vhjb.py (the BASELINE workload); tanh = the cartpole notebook's network")
-    ap.add_argument("--arithmetic", default="f32", choices=["f32", "bf16x3"],
-                    help="value-network arithmetic of the fused kernels: f32 = float32 MFMA (an fmaf chain, bitwise); bf16x3 = every float32 operand split "
-                         "exactly into three bfloat16 pieces, six piece products on the bf16 matrix cores (HJBX_OPT_MLP_ARITHMETIC)")
+    ap.add_argument("--arithmetic", default="f32", choices=["f32", "bf16x3", "f16x2"],
+                    help="value-network arithmetic of the fused kernels (HJBX_OPT_MLP_ARITHMETIC): f32 = float32 MFMA (an fmaf chain, bitwise); bf16x3 = every "
+                         "float32 operand split exactly into three bfloat16 pieces, six piece products on the bf16 matrix cores; f16x2 = operands scaled per "
+                         "environment and rounded to two float16 pieces (22 bits), three piece products on the f16 matrix cores")
     ap.add_argument("--chunk", type=int, default=0, help="steps per persistent launch (0 = all K steps in one launch)")
     ap.add_argument("--prewarm", type=float, default=0.3, help="seconds of untimed clock pre-warm on scratch state before the W warm-up steps (0 for counter runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -241,15 +242,17 @@ def mfma_roofline(wl, launches, B):
     launch_ms = ms * steps_per_launch
     ach = wl["flops_per_env"] * B / (ms * 1e-3) / 1e12
     alg, meas = rollout_traffic_model(wl["n"], wl["m"], B, steps_per_launch)
-    if ARITHMETIC == "bf16x3":
-        # executed matrix-core work: layers 2, 3 forward and backward as six bf16 piece products each (layer 1 stays on the f32 MFMA and is
-        # not counted); priced against the dense bf16 peak
-        executed = 6 * 4.0 * (128 * 128 + 128 * 64)
+    if ARITHMETIC != "f32":
+        # executed matrix-core work: layers 2, 3 forward and backward as six bf16 (three f16) piece products each (layer 1 stays on the f32
+        # MFMA and is not counted); priced against the dense bf16 / f16 peak
+        pieces = 6 if ARITHMETIC == "bf16x3" else 3
+        executed = pieces * 4.0 * (128 * 128 + 128 * 64)
         ach16 = executed * B / (ms * 1e-3) / 1e12
-        return dict(bound="mfma", kernel="k_vhjb_rollout_mfma<bf16x3> (hjbx_vhjb_rollout_f32, HJBX_OPT_MLP_ARITHMETIC=1)", achieved=ach16,
-                    peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach16 / MFMA_BF16_PEAK_TFLOPS, traffic=meas, traffic_algorithmic=alg,
+        return dict(bound="mfma", kernel=f"k_vhjb_rollout_mfma<{ARITHMETIC}> (hjbx_vhjb_rollout_f32, HJBX_OPT_MLP_ARITHMETIC={1 if pieces == 6 else 2})",
+                    achieved=ach16, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach16 / MFMA_BF16_PEAK_TFLOPS, traffic=meas, traffic_algorithmic=alg,
                     avg_launch_ms=launch_ms, steps_per_launch=steps_per_launch, flop_per_env_step=executed,
-                    note="achieved = EXECUTED bf16 MFMA flops (6 piece products per float32 product); the float32-equivalent rate is f32_equivalent",
+                    note=f"achieved = EXECUTED 16-bit MFMA flops ({pieces} piece products per float32 product) against the dense bf16 / f16 peak; "
+                         "the float32-equivalent rate is f32_equivalent",
                     f32_equivalent=ach, f32_equivalent_over_f32_mfma_peak=ach / MFMA_F32_PEAK_TFLOPS)
     return dict(bound="mfma", kernel="k_vhjb_rollout_mfma (hjbx_vhjb_rollout_f32)", achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=meas, traffic_algorithmic=alg, avg_launch_ms=launch_ms, steps_per_launch=steps_per_launch,
@@ -422,7 +425,7 @@ def main():
     from q_learning_with_hjb_amd import _abi, _ops
     global ARITHMETIC
     ARITHMETIC = args.arithmetic
-    _abi.set_option(_abi.OPT_MLP_ARITHMETIC, 1 if args.arithmetic == "bf16x3" else 0)
+    _abi.set_option(_abi.OPT_MLP_ARITHMETIC, {"f32": 0, "bf16x3": 1, "f16x2": 2}[args.arithmetic])
 
     def barrier():
         if dist is not None:
@@ -462,7 +465,8 @@ def main():
     out = dict(metric="env-steps/sec (batched HJB rollouts), cartpole batch=2^20" if args.system == "cartpole" else
                f"env-steps/sec (batched HJB rollouts), {args.system}", value=value, unit="env-steps/s", n_gpus=world,
                steps=K, warmup=W, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None,
-               dtype="f32" if args.arithmetic == "f32" else "f32 (value-network products as 3-way bf16 splits on the bf16 MFMA, f32 accumulation)",
+               dtype={"f32": "f32", "bf16x3": "f32 (value-network products as exact 3-way bf16 splits on the bf16 MFMA, f32 accumulation)",
+                      "f16x2": "f32 (value-network products as scaled 2-way f16 splits, 22 bits, on the f16 MFMA, f32 accumulation)"}[args.arithmetic],
                data="synthetic", reps=reps, ms_per_step_min=float(walls.min()) / K * 1e3, ms_per_step_max=float(walls.max()) / K * 1e3,
                config=dict(workload=wl["label"], batch_per_gpu=B, global_batch=global_batch,
                            state_dim=n, control_dim=m, integrator=args.integrator, mlp=f"{n}-128-128-64 {args.activation}, no bias",

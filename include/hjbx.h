@@ -101,10 +101,14 @@ typedef enum hjbx_option {
     HJBX_OPT_STREAM_ROWS = 2,              /* TUNING: rows per thread of the float32 streaming kernels (simulate, vhjb_step, hjb_residual):
                                               1, 2 or 4; 0 (default) = the library's choice */
     HJBX_OPT_MLP_ARITHMETIC = 3            /* arithmetic of the ReLU value network inside hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 (THE ONE KNOB
-                                              THAT CHANGES RESULTS, within float32 rounding): 0 (default) = float32 MFMA, bitwise an fmaf chain;
-                                              1 = every float32 operand split exactly into three bfloat16 pieces, the six largest piece products
-                                              on the bf16 matrix cores with float32 accumulation (dropped products <= 2^-22 of each term; layer 1
-                                              and everything outside the network stay float32).  tanh networks ignore it. */
+                                              THAT CHANGES RESULTS, within float32 rounding; inputs, outputs, accumulation, layer 1 and everything
+                                              outside the network are float32 in every mode; tanh networks ignore it):
+                                              0 (default) = float32 MFMA, bitwise an fmaf chain;
+                                              1 = bf16x3: every float32 operand split EXACTLY into three bfloat16 pieces, the six largest piece
+                                                  products on the bf16 matrix cores (dropped products <= 2^-23 of each term);
+                                              2 = f16x2: every operand scaled by a power of two (per weight matrix / per environment and
+                                                  product) and rounded to two float16 pieces = 22 significant bits, the three largest piece
+                                                  products on the f16 matrix cores (perturbation <= 3 x 2^-22 of each term). */
 } hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */

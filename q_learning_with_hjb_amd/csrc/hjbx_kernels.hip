@@ -804,7 +804,7 @@ int hjbx_device_count(void) {
 
 int hjbx_set_option(int option, int value) {
     HJBX_REQUIRE(option == HJBX_OPT_ROLLOUT_SCHEDULE || option == HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS || option == HJBX_OPT_STREAM_ROWS || option == HJBX_OPT_MLP_ARITHMETIC, "unknown option %d", option);
-    HJBX_REQUIRE(option != HJBX_OPT_MLP_ARITHMETIC || value <= 1, "mlp arithmetic must be 0 (f32 MFMA) or 1 (bf16x3-split MFMA), got %d", value);
+    HJBX_REQUIRE(option != HJBX_OPT_MLP_ARITHMETIC || value <= 2, "mlp arithmetic must be 0 (f32 MFMA), 1 (bf16x3-split MFMA) or 2 (f16x2-split MFMA), got %d", value);
     HJBX_REQUIRE(option != HJBX_OPT_ROLLOUT_SCHEDULE || value <= 1, "rollout schedule must be 0 or 1, got %d", value);
     HJBX_REQUIRE(value <= 64, "option value %d out of range", value);
     return value < 0 ? g_options[option].load() : g_options[option].exchange(value);

@@ -36,21 +36,22 @@
 #include "hjbx_host.hpp"
 #include "hjbx_mlp_core.hpp"
 #include "hjbx_mlp_x3.hpp"
+#include "hjbx_mlp_h2.hpp"
 
 using namespace hjbx;
 
 // launch shape: TL tiles of 32 environments per wave, WAVES waves per workgroup (one workgroup per CU).
 //   (TL, WAVES) = (1, 8): two waves per SIMD, 256 VGPRs each.   (2, 4): one wave per SIMD, 512 VGPRs.
-// This file is compiled once per variant (-DHJBX_MLP_ACT=0 relu, =1 tanh, =2 relu with the bf16x3-split arithmetic of hjbx_mlp_x3.hpp:
-// 30 kernel instantiations each, side by side); the relu object also carries the two C entry points, which validate and hand over to
-// the object of the requested variant.
+// This file is compiled once per variant (-DHJBX_MLP_ACT=0 relu, =1 tanh, =2 relu with the bf16x3-split arithmetic of hjbx_mlp_x3.hpp,
+// =3 relu with the f16x2-split arithmetic of hjbx_mlp_h2.hpp: 30 kernel instantiations each, side by side); the relu object also
+// carries the two C entry points, which validate and hand over to the object of the requested variant.
 #ifndef HJBX_MLP_ACT
-#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points), =1 (tanh) and =2 (relu, bf16x3-split MFMA)"
+#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points), =1 (tanh), =2 (relu, bf16x3-split MFMA) and =3 (relu, f16x2-split MFMA)"
 #endif
-static constexpr bool kX3 = HJBX_MLP_ACT == 2;
-static constexpr int kAct = kX3 ? HJBX_ACT_RELU : HJBX_MLP_ACT;
+static constexpr int kArith = HJBX_MLP_ACT == 2 ? 1 : HJBX_MLP_ACT == 3 ? 2 : 0;  // 0 = f32 MFMA, 1 = bf16x3, 2 = f16x2 (HJBX_OPT_MLP_ARITHMETIC)
+static constexpr int kAct = kArith ? HJBX_ACT_RELU : HJBX_MLP_ACT;
 static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH, "fused kernels exist for relu and tanh");
-template <int N, bool X3> using MlpLdsT = std::conditional_t<X3, MlpLdsX3<N>, MlpLds<N>>;
+template <int N, int AR> using MlpLdsT = std::conditional_t<AR == 1, MlpLdsX3<N>, std::conditional_t<AR == 2, MlpLdsH2<N>, MlpLds<N>>>;
 #define HJBX_MLP_CAT2(a, b) a##b
 #define HJBX_MLP_CAT(a, b) HJBX_MLP_CAT2(a, b)
 #define HJBX_MLP_SYM(name) HJBX_MLP_CAT(name, HJBX_MLP_ACT)
@@ -59,6 +60,9 @@ template <int N, bool X3> using MlpLdsT = std::conditional_t<X3, MlpLdsX3<N>, Ml
 HJBX_HIDDEN int hjbx_mlp_value_grad_act0(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_value_grad_act1(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_value_grad_act2(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_value_grad_act3(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_rollout_act3(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act2(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
                                       float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act0(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
@@ -74,26 +78,28 @@ HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, cons
 #endif
 
 // ---- kernel 1: V and dV/dx for a batch of states (hjbx_value_grad_f32) ---------------------------------------
-template <typename S, int TL, int WAVES, int ACT, bool X3>
+template <typename S, int TL, int WAVES, int ACT, int AR>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys, MlpP<S::N> p, const float* __restrict__ W1g,
                                                                          const float* __restrict__ W2g, const float* __restrict__ W3g,
                                                                          const float* __restrict__ x, float* __restrict__ Vout,
                                                                          float* __restrict__ gout, int64_t B, int64_t ngroups) {
     constexpr int N = S::N;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
-    static_assert(!X3 || TL == 1, "the bf16x3-split chain holds one tile per wave");
-    __shared__ __attribute__((aligned(256))) MlpLdsT<N, X3> L;
+    static_assert(AR == 0 || TL == 1, "the split-operand chains hold one tile per wave");
+    __shared__ __attribute__((aligned(256))) MlpLdsT<N, AR> L;
     const int tid = threadIdx.x;
     if (tid == 0) L.next = WAVES;  // groups 0..WAVES-1 of the range are taken statically
 #ifdef HJBX_DIAG_CLOCK
     const unsigned long long tentry = __builtin_amdgcn_s_memrealtime();
 #endif
-    if constexpr (X3) mlp_fill_lds_x3<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    if constexpr (AR == 1) mlp_fill_lds_x3<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    else if constexpr (AR == 2) mlp_fill_lds_h2<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     else mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const auto c = [&] {
-        if constexpr (X3) return mlp_ctx_x3<N>(L, lane);
+        if constexpr (AR == 1) return mlp_ctx_x3<N>(L, lane);
+        else if constexpr (AR == 2) return mlp_ctx_h2<N>(L, lane);
         else return mlp_ctx<N>(L, lane);
     }();
     const int i = c.i, h = c.h;
@@ -136,7 +142,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_value_grad_mfma(S sys
         load_rows(grp_next, xn);
 
         float V[TL], g[TL][N];
-        if constexpr (X3) mlp_value_grad_x3<S>(sys, p, c, xs, gout != nullptr, V, g);
+        if constexpr (AR == 1) mlp_value_grad_x3<S>(sys, p, c, xs, gout != nullptr, V, g);
+        else if constexpr (AR == 2) mlp_value_grad_h2<S>(sys, p, c, xs, gout != nullptr, V, g);
         else mlp_value_grad<S, TL, ACT>(sys, p, c, xs, gout != nullptr, V, g);
 #pragma unroll
         for (int t = 0; t < TL; ++t) {
@@ -191,7 +198,7 @@ static constexpr int kWsOpen = kWsFlags + kMaxGrid;     // [kMaxGrid] next uncla
 static constexpr int kWsWords = kWsOpen + kMaxGrid;
 #define HJBX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-template <int INTEG, typename S, int WAVES, int ACT, bool X3>
+template <int INTEG, typename S, int WAVES, int ACT, int AR>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
                                                                            Limits<float, S::M> lim_k, const float* __restrict__ W1g,
                                                                            const float* __restrict__ W2g, const float* __restrict__ W3g,
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
                                                                            int64_t ngroups, unsigned* ws, int sched) {
     constexpr int N = S::N, M = S::M;
     static_assert(N % 2 == 0, "state dimension must be even (k-steps of 2)");
-    __shared__ __attribute__((aligned(256))) MlpLdsT<N, X3> L;
+    __shared__ __attribute__((aligned(256))) MlpLdsT<N, AR> L;
     // System, task, limits and normalisation constants are staged in LDS: as kernel arguments they are ~100-250 wave-uniform
     // scalars that do not fit the SGPR file next to the address arithmetic, and hipcc spilled them to VGPR lanes
     // (hundreds of v_readlane / v_writelane per step, some inside the MFMA chains).  LDS broadcast reads cost no SGPRs.
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
         __hip_atomic_fetch_add(ws + kWsStarted, 1u, HJBX_RLX_AGENT);
         sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k;
     }
-    if constexpr (X3) mlp_fill_lds_x3<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    if constexpr (AR == 1) mlp_fill_lds_x3<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    else if constexpr (AR == 2) mlp_fill_lds_h2<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     else mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     __syncthreads();
     const S& sys = sys_s;
@@ -235,7 +243,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     const Limits<float, M>& lim = lim_s;
     const int lane = tid & 63, wave = tid >> 6;
     const auto c = [&] {
-        if constexpr (X3) return mlp_ctx_x3<N>(L, lane);
+        if constexpr (AR == 1) return mlp_ctx_x3<N>(L, lane);
+        else if constexpr (AR == 2) return mlp_ctx_h2<N>(L, lane);
         else return mlp_ctx<N>(L, lane);
     }();
     const int i = c.i, h = c.h;
@@ -328,7 +337,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
                 cst = dn = res = 0.0f;
             } else {
                 float V[1], g[1][N];
-                if constexpr (X3) mlp_value_grad_x3<S>(sys, p, c, xs, true, V, g);
+                if constexpr (AR == 1) mlp_value_grad_x3<S>(sys, p, c, xs, true, V, g);
+                else if constexpr (AR == 2) mlp_value_grad_h2<S>(sys, p, c, xs, true, V, g);
                 else mlp_value_grad<S, 1, ACT>(sys, p, c, xs, true, V, g);
                 vhjb_step_env<INTEG>(sys, tk, lim, t_first + k, T_max, o.resid != nullptr, xs[0], g[0], ds, xo, u, cst, dn, res);
             }
@@ -386,7 +396,7 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
     // one resident workgroup per CU (106 KB of LDS each); small batches are spread one tile group per CU
     // rather than packed eight to a workgroup, so up to n_cu matrix pipes work on them
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;
-    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, kAct, kX3>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
+    hipLaunchKernelGGL((k_value_grad_mfma<S, TL, WAVES, kAct, kArith>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)st, sys, p,
                        (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, x, V, g, B, ngroups);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_grad_f32: %s", hipGetErrorString(e));
@@ -397,6 +407,9 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
 int HJBX_MLP_SYM(hjbx_mlp_value_grad_act)(const hjbx_system* sys, const hjbx_mlp* mlp, const float* x, float* V, float* g, int64_t B, void* stream) {
 #ifdef HJBX_MLP_DEV  // development builds: cartpole only (30 instantiations take a minute per variant)
     if (sys->kind == HJBX_SYS_CARTPOLE) { Cartpole<float> c{}; return launch_value_grad(c, mlp, x, V, g, B, stream); }
+#ifdef HJBX_MLP_DEV_QUAD2D
+    if (sys->kind == HJBX_SYS_QUAD2D) { Quad2D<float> q{}; return launch_value_grad(q, mlp, x, V, g, B, stream); }
+#endif
     return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_grad_f32: development build (cartpole only)");
 #else
     switch (sys->kind) {
@@ -436,8 +449,10 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: normalization_std[%d] is zero", k);
     if (mlp->activation == HJBX_ACT_TANH) return hjbx_mlp_value_grad_act1(sys, mlp, x, V, g, B, stream);
-    return hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 1 ? hjbx_mlp_value_grad_act2(sys, mlp, x, V, g, B, stream)
-                                                           : hjbx_mlp_value_grad_act0(sys, mlp, x, V, g, B, stream);
+    const int arith = hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC);
+    return arith == 1 ? hjbx_mlp_value_grad_act2(sys, mlp, x, V, g, B, stream)
+         : arith == 2 ? hjbx_mlp_value_grad_act3(sys, mlp, x, V, g, B, stream)
+                      : hjbx_mlp_value_grad_act0(sys, mlp, x, V, g, B, stream);
 }
 #endif
 
@@ -468,7 +483,7 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     if (grid > kMaxGrid) grid = kMaxGrid;
     const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
     auto launch = [&](auto integ) {
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, kAct, kX3>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<decltype(integ)::value, S, WAVES, kAct, kArith>), dim3((unsigned)grid), dim3(WAVES * 64), 0,
                            (hipStream_t)st, sys, p, tk, lim, W1, W2, W3, t_first, n_steps, T_max, x, order, o, B, ngroups, (unsigned*)workspace, sched);
     };
     if (integrator == HJBX_EULER) launch(std::integral_constant<int, 0>{});
@@ -493,7 +508,7 @@ int HJBX_MLP_SYM(hjbx_mlp_rollout_act)(const hjbx_system* sys, const hjbx_task* 
         RolloutOut<4, 1> o{traj, u_log, cost, done, resid, done_step, x_out};
         const int64_t ngroups = (B + 31) / 32;
         int64_t grid = ngroups < 256 ? ngroups : 256;
-        hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, Cartpole<float>, WAVES, kAct, kX3>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)stream, S, p,
+        hipLaunchKernelGGL((k_vhjb_rollout_mfma<0, Cartpole<float>, WAVES, kAct, kArith>), dim3((unsigned)grid), dim3(WAVES * 64), 0, (hipStream_t)stream, S, p,
                            make_task<float, 4, 1>(task), make_limits<float, 1>(sys), (const float*)mlp->W1, (const float*)mlp->W2, (const float*)mlp->W3, t_first,
                            n_steps, T_max, x, env_order, o, B, ngroups, (unsigned*)workspace, hjbx_option_value(HJBX_OPT_ROLLOUT_SCHEDULE));
         return hipGetLastError() == hipSuccess ? HJBX_OK : hjbx_set_error(HJBX_EHIP, "launch");
@@ -541,8 +556,8 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: normalization_std[%d] is zero", k);
     if (mlp->activation == HJBX_ACT_TANH)
         return hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
-    return hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 1
-               ? hjbx_mlp_rollout_act2(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream)
-               : hjbx_mlp_rollout_act0(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
+    const int arith = hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC);
+    return (arith == 1 ? hjbx_mlp_rollout_act2 : arith == 2 ? hjbx_mlp_rollout_act3 : hjbx_mlp_rollout_act0)(
+        sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
 }
 #endif

@@ -127,6 +127,19 @@ __device__ __forceinline__ void mfma_chain(f32x16 (&acc)[TL][NOUT], float (&ring
     mfma_chain_step<Off, NSTEPS, NOUT, DEPTH, TL, 0>(acc, ring, b, base, getB);
 }
 
+// hipcc's hazard recogniser does not look inside inline asm: an asm VALU statement (relu_mask, mask_apply, v_fma_mix) that READS an
+// accumulator while the MFMA that writes it is still in flight gets no wait states and sees stale registers -- and such statements are
+// pure, so the scheduler may place them directly behind the last MFMA of a chain (seen on one instantiation only, the
+// planar quadrotor's f16x2 kernel: its last 32 layer-1 units were masked with half-written values).  Every chain whose results are
+// consumed by asm statements is therefore followed by this barrier: enough idle issue
+// slots for the last MFMA to retire (8-pass MFMA: 11 wait states, 16-pass: 19), fenced so that nothing moves across it.
+template <int PASSES> __device__ __forceinline__ void mfma_results_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PASSES > 8) asm volatile("s_nop 15\n\ts_nop 7");
+    else asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // byte offsets (from the lane-dependent base) of the A operand of (step, output block) for each product
 struct OffW1F { static constexpr int at(int st, int fb) { return (2 * st * kLD1 + 32 * fb) * 4; } };
 struct OffW2F { static constexpr int at(int st, int fb) { return ((32 * (st >> 4) + perm(st & 15)) * kLD2 + 32 * fb) * 4; } };

@@ -177,14 +177,40 @@ template <typename Dir, int K, int O, int NOUT> __device__ __forceinline__ void 
 }
 
 // pieces of one pair of B-operand elements (2 jj, 2 jj + 1) -> dword jj of the three fragments
-template <int NIN, int K, int JJ> __device__ __forceinline__ void x3_split(const f32x16 (&in)[NIN], uint32_t (&Bp)[3][4]) {
-    const float x0 = in[K >> 1][8 * (K & 1) + 2 * JJ], x1 = in[K >> 1][8 * (K & 1) + 2 * JJ + 1];
+// v = relu(v) and bit BIT of m = [v > 0]
+template <int BIT> __device__ __forceinline__ void relu_mask(float& v, uint32_t& m) {
+    v = relu1(v);
+    uint32_t t;
+    asm("v_min_u32_e32 %0, 1, %2\n\tv_lshl_or_b32 %1, %0, %3, %1" : "=&v"(t), "+v"(m) : "v"(v), "n"(BIT));
+}
+// x * [bit BIT of m]
+template <int BIT> __device__ __forceinline__ float mask_apply(float x, uint32_t m) {
+    float y;
+    asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32_e32 %0, %0, %3" : "=&v"(y) : "v"(m), "n"(BIT), "v"(x));
+    return y;
+}
+
+// What happens to the chain's input registers on their way into the B fragments (PRE): the element-wise work between two products runs
+// inside the consuming chain, two elements per unit next to their split, instead of in a VALU-only pass in front of it (where this
+// wave issues no MFMA for ~500 instructions and relies on its SIMD partner being inside a chain at that moment).
+enum { kPreNone = 0, kPreReluMask = 1, kPreMaskApply = 2 };  // relu + record [v > 0] in the mask | multiply by the recorded mask bit
+
+template <int NIN, int K, int JJ, int PRE> __device__ __forceinline__ void x3_split(const f32x16 (&in)[NIN], uint32_t (&Bp)[3][4], uint32_t (&m)[2]) {
+    constexpr int kb = K >> 1, r0 = 8 * (K & 1) + 2 * JJ;  // registers r0, r0 + 1 of block kb: mask bits 16 (kb & 1) + r of m[kb >> 1]
+    float x0 = in[kb][r0], x1 = in[kb][r0 + 1];
+    if constexpr (PRE == kPreReluMask) {
+        relu_mask<16 * (kb & 1) + r0>(x0, m[kb >> 1]);
+        relu_mask<16 * (kb & 1) + r0 + 1>(x1, m[kb >> 1]);
+    } else if constexpr (PRE == kPreMaskApply) {
+        x0 = mask_apply<16 * (kb & 1) + r0>(x0, m[kb >> 1]);
+        x1 = mask_apply<16 * (kb & 1) + r0 + 1>(x1, m[kb >> 1]);
+    }
     x3_split_pair(x0, x1, Bp[0][JJ], Bp[1][JJ], Bp[2][JJ]);
 }
 
-template <typename Dir, int NK, int NOUT, int NIN, int U>
+template <typename Dir, int NK, int NOUT, int NIN, int PRE, int U>
 __device__ __forceinline__ void x3_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], const uint32_t (&base)[2], X3Ops (&ring)[3],
-                                        uint32_t (&Bp)[2][3][4], uint32_t& root) {
+                                        uint32_t (&Bp)[2][3][4], uint32_t& root, uint32_t (&m)[2]) {
     constexpr int NU = NK * NOUT;
     if constexpr (U < NU) {
         constexpr int K = U / NOUT, O = U % NOUT;
@@ -194,8 +220,8 @@ __device__ __forceinline__ void x3_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[
         if constexpr (K + 1 < NK) {
             constexpr int PP = 4 / NOUT;
             if constexpr (PP >= 1) {
-                x3_split<NIN, K + 1, O * PP>(in, Bp[(K + 1) & 1]);
-                if constexpr (PP == 2) x3_split<NIN, K + 1, O * PP + 1>(in, Bp[(K + 1) & 1]);
+                x3_split<NIN, K + 1, O * PP, PRE>(in, Bp[(K + 1) & 1], m);
+                if constexpr (PP == 2) x3_split<NIN, K + 1, O * PP + 1, PRE>(in, Bp[(K + 1) & 1], m);
             }
         }
         constexpr int ahead = (NU - 1 - U < 2 ? NU - 1 - U : 2) * 6;
@@ -215,13 +241,14 @@ __device__ __forceinline__ void x3_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[
         acc = MFMA_BF16(ah, bh, acc);
         out[O] = acc;
         __builtin_amdgcn_sched_barrier(0);
-        x3_unit<Dir, NK, NOUT, NIN, U + 1>(out, in, base, ring, Bp, root);
+        x3_unit<Dir, NK, NOUT, NIN, PRE, U + 1>(out, in, base, ring, Bp, root, m);
     }
 }
 
-// out[o] (+)= W-image product of `in` (NIN 32-feature blocks already holding the activated / masked values); NK = 2 NIN k-steps
-template <typename Dir, int NOUT, int NIN>
-__device__ __forceinline__ void x3_chain(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], const uint32_t (&base)[2]) {
+// out[o] (+)= W-image product of PRE(`in`) (NIN 32-feature blocks); NK = 2 NIN k-steps.  `m`: the ReLU mask PRE records into / applies
+// (128 bits per lane: bit 16 (fb & 1) + r of m[fb >> 1] belongs to register r of block fb).
+template <typename Dir, int NOUT, int NIN, int PRE>
+__device__ __forceinline__ void x3_chain(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], const uint32_t (&base)[2], uint32_t (&m)[2]) {
     constexpr int NK = 2 * NIN;
     static_assert(NOUT == 2 || NOUT == 4, "");
     X3Ops ring[3];
@@ -230,35 +257,14 @@ __device__ __forceinline__ void x3_chain(f32x16 (&out)[NOUT], const f32x16 (&in)
     x3_issue<Dir, 0, 0, NOUT>(ring[0], base, root);
     x3_issue<Dir, 1 / NOUT, 1 % NOUT, NOUT>(ring[1], base, root);
     __builtin_amdgcn_sched_barrier(0);
-    x3_split<NIN, 0, 0>(in, Bp[0]);
-    x3_split<NIN, 0, 1>(in, Bp[0]);
-    x3_split<NIN, 0, 2>(in, Bp[0]);
-    x3_split<NIN, 0, 3>(in, Bp[0]);
-    x3_unit<Dir, NK, NOUT, NIN, 0>(out, in, base, ring, Bp, root);
+    x3_split<NIN, 0, 0, PRE>(in, Bp[0], m);
+    x3_split<NIN, 0, 1, PRE>(in, Bp[0], m);
+    x3_split<NIN, 0, 2, PRE>(in, Bp[0], m);
+    x3_split<NIN, 0, 3, PRE>(in, Bp[0], m);
+    x3_unit<Dir, NK, NOUT, NIN, PRE, 0>(out, in, base, ring, Bp, root, m);
+    mfma_results_barrier<8>();
 }
 
-// v = relu(v) and bit BIT of m = [v > 0]
-template <int BIT> __device__ __forceinline__ void relu_mask(float& v, uint32_t& m) {
-    v = relu1(v);
-    uint32_t t;
-    asm("v_min_u32_e32 %0, 1, %2\n\tv_lshl_or_b32 %1, %0, %3, %1" : "=&v"(t), "+v"(m) : "v"(v), "n"(BIT));
-}
-// x * [bit BIT of m]
-template <int BIT> __device__ __forceinline__ float mask_apply(float x, uint32_t m) {
-    float y;
-    asm("v_bfe_i32 %0, %1, %2, 1\n\tv_and_b32_e32 %0, %0, %3" : "=&v"(y) : "v"(m), "n"(BIT), "v"(x));
-    return y;
-}
-
-template <int FB, int R> __device__ __forceinline__ void relu_mask_block(f32x16 (&a)[4], uint32_t (&m)[2]) {
-    if constexpr (FB < 4) {
-        float v = a[FB][R];
-        relu_mask<16 * (FB & 1) + R>(v, m[FB >> 1]);
-        a[FB][R] = v;
-        if constexpr (R + 1 < 16) relu_mask_block<FB, R + 1>(a, m);
-        else relu_mask_block<FB + 1, 0>(a, m);
-    }
-}
 template <int FB, int R> __device__ __forceinline__ void mask_apply_block(f32x16 (&a)[4], const uint32_t (&m)[2]) {
     if constexpr (FB < 4) {
         const float v = a[FB][R];
@@ -289,23 +295,22 @@ __device__ __forceinline__ void mlp_value_grad_x3(const S& sys, const MlpP<S::N>
     f32x16 a1[1][4];
     zero_acc(a1);
     mfma_chain<OffW1F, N / 2, 4, 2, 1>(a1, ring4, c.w1f, [&](int st, int t) { return h ? z[t][2 * st + 1] : z[t][2 * st]; });
-    uint32_t m1[2] = {0u, 0u}, m2[2] = {0u, 0u};
-    relu_mask_block<0, 0>(a1[0], m1);
+    mfma_results_barrier<16>();
+    uint32_t m1[2] = {0u, 0u}, m2[2] = {0u, 0u}, m0[2] = {0u, 0u};
     // ---- layer 2 ------------------------------------------------------------------------------------------
     f32x16 a2[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a2[o][r] = 0.f;
-    x3_chain<DirFwd, 4, 4>(a2, a1[0], c.f2);
-    relu_mask_block<0, 0>(a2, m2);
+    x3_chain<DirFwd, 4, 4, kPreReluMask>(a2, a1[0], c.f2, m1);  // relu(a1) and its mask m1 on the way in
     // ---- layer 3 ------------------------------------------------------------------------------------------
     f32x16 y[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[o][r] = 0.f;
-    x3_chain<DirFwd, 2, 4>(y, a2, c.f3);
+    x3_chain<DirFwd, 2, 4, kPreReluMask>(y, a2, c.f3, m2);
     float vpart = 0.f;
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
@@ -313,24 +318,22 @@ __device__ __forceinline__ void mlp_value_grad_x3(const S& sys, const MlpP<S::N>
         for (int r = 0; r < 16; ++r) {
             const float yy = y[ob][r];
             vpart = fmaf(yy, yy, vpart);
-            y[ob][r] = yy + yy;  // dV/dy
         }
     V[0] = vpart + __shfl_xor(vpart, 32, 64) + p.eps_s * ee;
     if (!want_grad) return;
-    // ---- backward 3, 2 --------------------------------------------------------------------------------------
+    // ---- backward 3, 2 (on y instead of dV/dy = 2 y: see the last line) ------------------------------------------
     f32x16 d2[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2[o][r] = 0.f;
-    x3_chain<DirBwd, 4, 2>(d2, y, c.t3);
-    mask_apply_block<0, 0>(d2, m2);
+    x3_chain<DirBwd, 4, 2, kPreNone>(d2, y, c.t3, m0);
     f32x16 d1[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[o][r] = 0.f;
-    x3_chain<DirBwd, 4, 4>(d1, d2, c.t2);
+    x3_chain<DirBwd, 4, 4, kPreMaskApply>(d1, d2, c.t2, m2);
     mask_apply_block<0, 0>(d1, m1);
     // ---- backward 1 on the VALU (as in mlp_value_grad) ---------------------------------------------------------
     f32x2 part[NP / 2];
@@ -353,6 +356,6 @@ __device__ __forceinline__ void mlp_value_grad_x3(const S& sys, const MlpP<S::N>
     for (int k = 0; k < N; ++k) {
         const float pk = part[k >> 1][k & 1];
         const float v = pk + __shfl_xor(pk, 32, 64);
-        g[0][k] = v * p.istd[k] + 2.f * p.eps_s * e[k];
+        g[0][k] = (v + v) * p.istd[k] + 2.f * p.eps_s * e[k];  // dV/dy = 2 y: the backward products ran on y, the factor 2 (exact) comes in here
     }
 }

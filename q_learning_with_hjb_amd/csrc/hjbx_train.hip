@@ -85,6 +85,7 @@ template <int NB> __device__ __forceinline__ void store_tile_array(float* __rest
 // select, turned every mask bit into a v_cmp whose 64-bit lane mask it kept in an SGPR pair for all three uses, and spilled the
 // resulting 256 SGPRs to VGPR lanes: ~700 v_readlane / v_writelane / v_cndmask per tile (profiles: chains at 69 % of their MFMA time).
 __device__ __forceinline__ void relu_mask_build(const f32x16 (&hv)[4], uint32_t (&m)[2]) {
+    mfma_results_barrier<16>();   // hv comes straight out of an MFMA chain and is read by asm below (hjbx_mlp_core.hpp)
     m[0] = m[1] = 0u;
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb)
@@ -96,6 +97,7 @@ __device__ __forceinline__ void relu_mask_build(const f32x16 (&hv)[4], uint32_t 
         }
 }
 __device__ __forceinline__ void relu_mask_apply(f32x16 (&v)[4], const uint32_t (&m)[2]) {
+    mfma_results_barrier<16>();   // (as above)
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll

@@ -77,12 +77,16 @@ def wrapped_diff(a, b, angle_idx):
 ANGLE_IDX = {"linear": [], "cartpole": [1], "acrobot": [0, 1], "quad2d": [2], "nearhover": [3, 4]}
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+ARITHMETICS = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+
+
+@pytest.fixture(params=list(ARITHMETICS))
 def arith(request):
-    """Runs a GPU test in both value-network arithmetics of the fused kernels (hjbx.h HJBX_OPT_MLP_ARITHMETIC) against the SAME bounds:
+    """Runs a GPU test in every value-network arithmetic of the fused kernels (hjbx.h HJBX_OPT_MLP_ARITHMETIC) against the SAME bounds:
     f32 = float32 MFMA (bitwise an fmaf chain); bf16x3 = each float32 operand split exactly into three bfloat16 pieces, six piece products
-    on the bf16 matrix cores with float32 accumulation (csrc/hjbx_mlp_x3.hpp)."""
+    on the bf16 matrix cores (csrc/hjbx_mlp_x3.hpp); f16x2 = each operand scaled per environment and rounded to two float16 pieces (22
+    bits), three piece products on the f16 matrix cores (csrc/hjbx_mlp_h2.hpp); float32 accumulation in all of them."""
     from q_learning_with_hjb_amd import _abi
-    prev = _abi.set_option(_abi.OPT_MLP_ARITHMETIC, 1 if request.param == "bf16x3" else 0)
+    prev = _abi.set_option(_abi.OPT_MLP_ARITHMETIC, ARITHMETICS[request.param])
     yield request.param
     _abi.set_option(_abi.OPT_MLP_ARITHMETIC, prev)

@@ -39,7 +39,7 @@ def audit(path):
         if not s or s.startswith(";") or s.startswith("."):
             continue
         if in_asm:
-            m = re.match(r"ds_read_b(?:32|64|128) (v\d+|v\[\d+:\d+\]),", s)
+            m = re.match(r"ds_read_b(?:32|64_tr_b16|64|128) (v\d+|v\[\d+:\d+\]),", s)
             if m:
                 pending.append(frozenset(regs_of(m.group(1))))
                 nreads += 1

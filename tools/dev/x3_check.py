@@ -34,14 +34,14 @@ def main():
             mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar)
             oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
             res = {}
-            for arith in (0, 1):
+            for arith in (0, 1, 2):
                 _abi.set_option(_abi.OPT_MLP_ARITHMETIC, arith)
                 V, gr = _ops.value_grad(d.system, vf.descriptor(), x)
                 torch.cuda.synchronize()
                 res[arith] = (V.cpu().numpy().astype(np.float64), gr.cpu().numpy().astype(np.float64))
             _abi.set_option(_abi.OPT_MLP_ARITHMETIC, 0)
             sv, sg = np.abs(oV).max(), np.abs(og).max()
-            for arith in (0, 1):
+            for arith in (0, 1, 2):
                 V, gr = res[arith]
                 eV = np.abs(V - oV) / (np.abs(oV) + 1e-3 * sv)
                 eg = np.abs(gr - og).max(1) / (np.abs(og).max(1) + 1e-3 * sg)
@@ -51,7 +51,7 @@ def main():
         B, T = (1 << 18 if name == "quad2d" else 1 << 20), 40
         g = torch.Generator(device="cuda").manual_seed(1)
         x0 = (torch.as_tensor(np.asarray(ctl.xf), device="cuda", dtype=torch.float32) + (torch.rand(B, d.state_dim, generator=g, device="cuda") * 2 - 1) * 0.3).contiguous()
-        for arith in (0, 1):
+        for arith in (0, 1, 2):
             _abi.set_option(_abi.OPT_MLP_ARITHMETIC, arith)
             ts = []
             for rep in range(4):
