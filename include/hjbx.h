@@ -91,7 +91,7 @@ typedef enum hjbx_controller_kind {
                                           the control of each step (time-to-origin loops of the time-optimal notebook,
                                           cell 9); done_step = index of that step */
 
-/* Process-wide tuning / test knobs (hjbx_set_option).  Options 0-2 do not change results. */
+/* Process-wide tuning / test knobs (hjbx_set_option; a negative value queries).  Options 0-2 do not change results. */
 typedef enum hjbx_option {
     HJBX_OPT_ROLLOUT_SCHEDULE = 0,         /* work distribution of hjbx_vhjb_rollout_f32: 0 (default) = equal static shares per workgroup, with
                                               the shares of workgroups that have not started taken over by the waves that finish first;
@@ -102,13 +102,16 @@ typedef enum hjbx_option {
                                               1, 2 or 4; 0 (default) = the library's choice */
     HJBX_OPT_MLP_ARITHMETIC = 3            /* arithmetic of the ReLU value network inside hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 (THE ONE KNOB
                                               THAT CHANGES RESULTS, within float32 rounding; inputs, outputs, accumulation, layer 1 and everything
-                                              outside the network are float32 in every mode; tanh networks ignore it):
-                                              0 (default) = float32 MFMA, bitwise an fmaf chain;
+                                              outside the network are float32 in every mode; tanh networks always run mode 0):
+                                              0 = float32 MFMA, bitwise an fmaf chain (the slowest: 1 / 16 of the 16-bit matrix rate);
                                               1 = bf16x3: every float32 operand split EXACTLY into three bfloat16 pieces, the six largest piece
                                                   products on the bf16 matrix cores (dropped products <= 2^-23 of each term);
-                                              2 = f16x2: every operand scaled by a power of two (per weight matrix / per environment and
-                                                  product) and rounded to two float16 pieces = 22 significant bits, the three largest piece
-                                                  products on the f16 matrix cores (perturbation <= 3 x 2^-22 of each term). */
+                                              2 (DEFAULT) = f16x2: every operand scaled by a power of two (per weight matrix / per environment
+                                                  and product) and rounded to two float16 pieces = 22 significant bits, the three largest
+                                                  piece products on the f16 matrix cores (perturbation <= 3 x 2^-22 = 7e-7 of each term,
+                                                  against the path's 1e-5 tolerance).
+                                              All three meet the same per-element parity bounds against the float64 oracle
+                                              (tests/test_gpu_f32_parity.py runs every test in every mode). */
 } hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */

@@ -215,6 +215,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"hjbx: {_LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the hot path)")
+        # PyTorch first: its wheel carries its own HIP runtime, and whichever libamdhip64 the process loads first serves both.  With
+        # libhjbx.so loaded first (e.g. build() then smoke() in one process) torch ends up on the system runtime and hipGetDevice
+        # reports no device; the other way round both use torch's copy and share its streams and allocations.
+        import torch  # noqa: F401
         L = C.CDLL(_LIB_PATH)
         L.hjbx_version.restype = C.c_int
         L.hjbx_last_error.restype = C.c_size_t

@@ -34,7 +34,7 @@ int hjbx_set_error(int code, const char* fmt, ...) {
 }
 
 // process-wide knobs (include/hjbx.h: hjbx_option)
-static std::atomic<int> g_options[4] = {{0}, {0}, {0}, {0}};
+static std::atomic<int> g_options[4] = {{0}, {0}, {0}, {2}};   // (HJBX_OPT_MLP_ARITHMETIC defaults to 2 = f16x2)
 int hjbx_option_value(int option) { return (option >= 0 && option < 4) ? g_options[option].load(std::memory_order_relaxed) : 0; }
 
 #define HJBX_REQUIRE(cond, ...)                                  \
