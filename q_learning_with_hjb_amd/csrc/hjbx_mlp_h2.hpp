@@ -181,22 +181,27 @@ __device__ __forceinline__ void h2_split(const f32x16 (&in)[NIN], float s, uint3
     h2_split_pair(x0, x1, s, Bp[0][JJ], Bp[1][JJ]);
 }
 
+// The LDS reads of a unit are issued kH2Depth units (3 x 96 matrix-pipe cycles) ahead of its MFMAs: with eight waves reading 85 B / clk
+// from the CU's LDS a read took longer than the two units of the first version to come back (SQ_WAIT_INST_ANY: 48 % of the wave cycles).
+static constexpr int kH2Depth = 3;   // x 4 reads per unit <= 15 (lgkmcnt is a 4-bit counter)
+
 template <typename Dir, int NK, int NOUT, int NIN, int PRE, int U>
-__device__ __forceinline__ void h2_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], uint32_t base, float s, H2Ops (&ring)[3], uint32_t (&Bp)[2][2][4],
-                                        uint32_t& root, uint32_t (&m)[2]) {
+__device__ __forceinline__ void h2_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], uint32_t base, float s, H2Ops (&ring)[kH2Depth + 1],
+                                        uint32_t (&Bp)[2][2][4], uint32_t& root, uint32_t (&m)[2]) {
     constexpr int NU = NK * NOUT;
     if constexpr (U < NU) {
         constexpr int K = U / NOUT, O = U % NOUT;
-        if constexpr (U + 2 < NU) h2_issue<Dir, (U + 2) / NOUT, (U + 2) % NOUT>(ring[(U + 2) % 3], base, root);
+        if constexpr (U + kH2Depth < NU)
+            h2_issue<Dir, (U + kH2Depth) / NOUT, (U + kH2Depth) % NOUT>(ring[(U + kH2Depth) % (kH2Depth + 1)], base, root);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (K + 1 < NK) {
             constexpr int PP = 4 / NOUT;
             h2_split<NIN, K + 1, O * PP, PRE>(in, s, Bp[(K + 1) & 1], m);
             if constexpr (PP == 2) h2_split<NIN, K + 1, O * PP + 1, PRE>(in, s, Bp[(K + 1) & 1], m);
         }
-        constexpr int ahead = (NU - 1 - U < 2 ? NU - 1 - U : 2) * 4;
+        constexpr int ahead = (NU - 1 - U < kH2Depth ? NU - 1 - U : kH2Depth) * 4;
         lds_wait<ahead>();
-        const H2Ops& o = ring[U % 3];
+        const H2Ops& o = ring[U % (kH2Depth + 1)];
         const u32x4 ah{o.r[0][0][0], o.r[0][0][1], o.r[0][1][0], o.r[0][1][1]};
         const u32x4 al{o.r[1][0][0], o.r[1][0][1], o.r[1][1][0], o.r[1][1][1]};
         const uint32_t(&B)[2][4] = Bp[K & 1];
@@ -228,11 +233,12 @@ __device__ __forceinline__ int h2_chain(f32x16 (&out)[NOUT], const f32x16 (&in)[
     static_assert(NOUT == 2 || NOUT == 4, "");
     const int k = scale_exponent<14>(h2_absmax<NIN, PRE == kPreReluMask>(in));
     const float s = pow2f(k);
-    H2Ops ring[3];
+    H2Ops ring[kH2Depth + 1];
     uint32_t Bp[2][2][4];
     uint32_t root;
     h2_issue<Dir, 0, 0>(ring[0], base, root);
     h2_issue<Dir, 1 / NOUT, 1 % NOUT>(ring[1], base, root);
+    if constexpr (kH2Depth > 2) h2_issue<Dir, 2 / NOUT, 2 % NOUT>(ring[2], base, root);
     __builtin_amdgcn_sched_barrier(0);
     h2_split<NIN, 0, 0, PRE>(in, s, Bp[0], m);
     h2_split<NIN, 0, 1, PRE>(in, s, Bp[0], m);
@@ -293,22 +299,40 @@ __device__ __forceinline__ void mlp_value_grad_h2(const S& sys, const MlpP<S::N>
     zero_blocks(d1);
     E += h2_chain<H2Bwd, 4, 4, kPreMaskApply>(d1, d2, c.t2, m2) + c.kw2;
     mask_apply_block<0, 0>(d1, m1);
+    // backward 1 on the VALU: each lane dots its 64 resident features with W1' rows (LDS broadcasts).  The rows are fetched GRP features at a
+    // time, one group ahead of the FMAs that use them: read-wait-use per feature left ~100 cycles of LDS latency exposed 64 times a tile.
     f32x2 part[NP / 2];
 #pragma unroll
     for (int k = 0; k < NP / 2; ++k) part[k] = f32x2{0.f, 0.f};
+    constexpr int GRP = NP <= 4 ? 8 : 4, NG = 64 / GRP;
+    float4 wbuf[2][GRP][NP / 4];
+    auto fetch = [&](int gi, float4 (&dst)[GRP][NP / 4]) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+        for (int j = 0; j < GRP; ++j) {
+            const int f = gi * GRP + j, kb = f >> 4, sreg = f & 15;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float dv = d1[kb][s];
+            for (int q = 0; q < NP / 4; ++q) dst[j][q] = c.w1t[(32 * kb + perm(sreg)) * (NP / 4) + q];
+        }
+    };
+    fetch(0, wbuf[0]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) fetch(gi + 1, wbuf[(gi + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            const int f = gi * GRP + j;
+            const float dv = d1[f >> 4][f & 15];
             const f32x2 dv2{dv, dv};
 #pragma unroll
             for (int q = 0; q < NP / 4; ++q) {
-                const float4 w = c.w1t[(32 * kb + perm(s)) * (NP / 4) + q];
+                const float4 w = wbuf[gi & 1][j][q];
                 part[2 * q + 0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dv2, part[2 * q + 0]);
                 part[2 * q + 1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dv2, part[2 * q + 1]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const float pk = part[k >> 1][k & 1];

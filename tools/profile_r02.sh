@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_r02
 mkdir -p $OUT
 R="rocprofv3 --output-format csv"
-# 1. kernel trace + stats of the bench command itself
+# 1. kernel trace + stats of the bench command itself (default arithmetic = f16x2; its secondary block runs the bf16x3 and f32 kernels too)
 $R --kernel-trace --stats -d $OUT/trace -- python3 bench.py > $OUT/bench_trace.json 2> $OUT/bench_trace.err || exit 1
 # 2. HBM traffic of the rollout kernel at two launch lengths (every launch of a run has the same length: warm-up = K, no pre-warm)
 for K in 100 20; do
@@ -14,8 +14,12 @@ for K in 100 20; do
     $R --pmc $C -d $OUT/pmc$K/$C -- python3 bench.py --no-secondary --no-cpu-baseline --prewarm 0 --steps $K --warmup $K --reps 3 > $OUT/pmc${K}_$C.json 2> $OUT/pmc${K}_$C.err || exit 1
   done
 done
-$R --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc100/SQ -- python3 bench.py --no-secondary --no-cpu-baseline --prewarm 0 --steps 100 --warmup 100 --reps 3 > $OUT/pmc100_SQ.json 2> $OUT/pmc100_SQ.err || exit 1
-# 3. the HBM-bound entry points: durations and counter bytes with buffers rotated through a 640 MB pool
+# 3. matrix-pipe / issue counters of the rollout kernel in each arithmetic
+for A in f16x2 bf16x3 f32; do
+  $R --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq_$A/a -- python3 bench.py --arithmetic $A --no-secondary --no-cpu-baseline --prewarm 0 --steps 100 --warmup 100 --reps 3 > $OUT/sq_${A}_a.json 2> $OUT/sq_${A}_a.err || exit 1
+  $R --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -d $OUT/sq_$A/b -- python3 bench.py --arithmetic $A --no-secondary --no-cpu-baseline --prewarm 0 --steps 100 --warmup 100 --reps 3 > $OUT/sq_${A}_b.json 2> $OUT/sq_${A}_b.err || exit 1
+done
+# 4. the HBM-bound entry points: durations and counter bytes with buffers rotated through a 640 MB pool
 $R --kernel-trace --stats -d $OUT/kb/trace -- python3 tools/kernel_bench.py --systems cartpole,acrobot,quad2d,nearhover --no-rollouts --json $OUT/kb.json > $OUT/kb.log 2>&1 || exit 1
 for C in FETCH_SIZE WRITE_SIZE; do
   $R --pmc $C -d $OUT/kb/$C -- python3 tools/kernel_bench.py --systems cartpole,acrobot,quad2d,nearhover --no-rollouts > $OUT/kb_$C.log 2>&1 || exit 1

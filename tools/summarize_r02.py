@@ -49,15 +49,17 @@ def main():
     st.sort(key=lambda r: -float(r["TotalDurationNs"]))
     with open(f"{dst}/r02_bench_kernel_stats.csv", "w", newline="") as f:
         f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py   (round 2; the timed region is 10 x one 200-step launch of "
-                "k_vhjb_rollout_mfma<0, Cartpole>; its other launches are the clock pre-warm (25 steps, no logs) and the 20 warm-up steps)\n")
+                "k_vhjb_rollout_mfma<0, Cartpole, 8, 0, 2> = the f16x2 kernel; its other launches are the clock pre-warm (25 steps, no logs) and the 20 warm-up steps; "
+                "<..., 0, 1> / <..., 0, 0> are the bf16x3 / f32 kernels of the secondary block)\n")
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in st:
             w.writerow([short(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
-    tr = [r for r in rows(f"{prof}/trace/*/*_kernel_trace.csv") if ROLL in r["Kernel_Name"]]
+    HEAD = "8, 0, 2>"      # ..., WAVES = 8, ACT = relu, ARITH = 2 (f16x2, the default arithmetic = the headline kernel)
+    tr = [r for r in rows(f"{prof}/trace/*/*_kernel_trace.csv") if ROLL in r["Kernel_Name"] and HEAD in r["Kernel_Name"].split("(")[0]]
     tr.sort(key=lambda r: int(r["Dispatch_Id"]))
     with open(f"{dst}/r02_bench_kernel_launches.csv", "w", newline="") as f:
-        f.write("# every dispatch of k_vhjb_rollout_mfma<0, hjbx::Cartpole<float>, 8, 0> in the run above, in order (ns)\n")
+        f.write("# every dispatch of k_vhjb_rollout_mfma<0, hjbx::Cartpole<float>, 8, 0, 2> (the f16x2 kernel) in the run above, in order (ns)\n")
         w = csv.writer(f)
         w.writerow(["Dispatch_Id", "DurationNs", "Grid_Size_X", "Workgroup_Size_X", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size"])
         for r in tr:
@@ -80,15 +82,34 @@ def main():
     a = (per[100] - per[20]) / (80.0 * B)
     b = (per[20] - 20 * a * B) / B
     n = 4
-    sq, meta = counter_means(prof, "pmc100/SQ", ROLL)
-    d = dict(counters=sq, meta=meta)
-    if "GRBM_GUI_ACTIVE" in sq and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
-        cyc = sq["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8          # the counter sums the 8 XCDs
-        d["gpu_cycles_per_launch"] = cyc
-        d["mfma_pipe_busy_fraction"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / 1024 / cyc
-    if "SQ_LDS_BANK_CONFLICT" in sq and "SQ_LDS_IDX_ACTIVE" in sq and sq["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] > 0:
-        d["lds_bank_conflict_fraction"] = sq["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / sq["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]
-    summ["k_vhjb_rollout_mfma cartpole, 100 steps per launch: SQ / GRBM pass"] = d
+    for arith in ("f16x2", "bf16x3", "f32"):
+        sq, meta = counter_means(prof, f"sq_{arith}/a", ROLL)
+        sq2, _ = counter_means(prof, f"sq_{arith}/b", ROLL)
+        sq.update(sq2)
+        if not sq:
+            continue
+        d = dict(counters=sq, meta=meta)
+        tile_steps = 100.0 * B / 32
+        if "GRBM_GUI_ACTIVE" in sq and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
+            cyc = sq["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8          # the counter sums the 8 XCDs
+            d["gpu_cycles_per_launch"] = cyc
+            d["mfma_pipe_busy_fraction"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / 1024 / cyc
+            d["gpu_cycles_per_tile_step_per_simd"] = cyc * 1024 / tile_steps
+            try:
+                with open(f"{prof}/sq_{arith}_a.json") as f:
+                    ms = json.loads(f.read())["roofline"]["avg_launch_ms"]
+                d["launch_ms_under_counters"] = ms
+                d["shader_clock_GHz"] = cyc / (ms * 1e-3) / 1e9
+            except (OSError, ValueError, KeyError):
+                pass
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU"):
+            if k in sq:
+                d[k.lower() + "_per_tile_step"] = sq[k]["mean_per_launch"] / tile_steps
+        if "SQ_WAIT_INST_ANY" in sq and "SQ_WAVE_CYCLES" in sq:
+            d["wave_cycles_waiting_fraction"] = sq["SQ_WAIT_INST_ANY"]["mean_per_launch"] / sq["SQ_WAVE_CYCLES"]["mean_per_launch"]
+        if "SQ_LDS_BANK_CONFLICT" in sq and "SQ_LDS_IDX_ACTIVE" in sq and sq["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] > 0:
+            d["lds_bank_conflict_fraction"] = sq["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / sq["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]
+        summ[f"k_vhjb_rollout_mfma cartpole, 100 steps per launch, arithmetic {arith}: SQ / GRBM passes"] = d
     summ["fit"] = dict(bytes_per_env_step=a, bytes_per_env_launch=b, algorithmic_per_env_step=4.0 * (n + 2), algorithmic_per_env_launch=4.0 * (3 * n + 2),
                        note="bytes(launch of k steps) = B (k a + b), from the 100- and 20-step passes")
     summ["bench_trace"] = dict(timed_launches_ns=long, median_ms_per_step=sorted(long)[len(long) // 2] / 200 / 1e6 if long else None)
@@ -134,7 +155,9 @@ def main():
     json.dump(out, open(f"{dst}/r02_kernel_bench.json", "w"), indent=1)
     print(json.dumps(summ["fit"], indent=1))
     print(json.dumps(summ["bench_trace"]))
-    print("mfma busy", d.get("mfma_pipe_busy_fraction"), "lds conflict", d.get("lds_bank_conflict_fraction"))
+    for k, v in summ.items():
+        if "SQ / GRBM" in k:
+            print(k, {kk: vv for kk, vv in v.items() if kk not in ("counters", "meta")})
     for r in out:
         print(f"{r['system']:10s} {r['kernel']:28s} {r['rocprof_avg_us'] or 0:7.2f} us  {r.get('achieved_GBs', 0):7.0f} GB/s  {100 * r.get('frac_of_8TBs', 0):5.1f} %  "
               f"counter/alg {r.get('counter_bytes_over_algorithmic', 0):.3f}")
