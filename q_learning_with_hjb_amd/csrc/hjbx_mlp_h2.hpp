@@ -300,24 +300,21 @@ __device__ __forceinline__ void mlp_value_grad_h2(const S& sys, const MlpP<S::N>
     E += h2_chain<H2Bwd, 4, 4, kPreMaskApply>(d1, d2, c.t2, m2) + c.kw2;
     mask_apply_block<0, 0>(d1, m1);
     // backward 1 on the VALU: each lane dots its 64 resident features with W1' rows (LDS broadcasts).  The rows are fetched GRP features at a
-    // time, one group ahead of the FMAs that use them: read-wait-use per feature left ~100 cycles of LDS latency exposed 64 times a tile.
+    // time (one wait per group): read-wait-use per feature left ~100 cycles of LDS latency exposed 64 times a tile.  (Fetching a group AHEAD of
+    // the FMAs as well cost 64 - 96 more registers and spilled in the n = 10 and m = 2 rollout kernels.)
     f32x2 part[NP / 2];
 #pragma unroll
     for (int k = 0; k < NP / 2; ++k) part[k] = f32x2{0.f, 0.f};
     constexpr int GRP = NP <= 4 ? 8 : 4, NG = 64 / GRP;
-    float4 wbuf[2][GRP][NP / 4];
-    auto fetch = [&](int gi, float4 (&dst)[GRP][NP / 4]) {
-#pragma unroll
-        for (int j = 0; j < GRP; ++j) {
-            const int f = gi * GRP + j, kb = f >> 4, sreg = f & 15;
-#pragma unroll
-            for (int q = 0; q < NP / 4; ++q) dst[j][q] = c.w1t[(32 * kb + perm(sreg)) * (NP / 4) + q];
-        }
-    };
-    fetch(0, wbuf[0]);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-        if (gi + 1 < NG) fetch(gi + 1, wbuf[(gi + 1) & 1]);
+        float4 wbuf[GRP][NP / 4];
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            const int f = gi * GRP + j;
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) wbuf[j][q] = c.w1t[(32 * (f >> 4) + perm(f & 15)) * (NP / 4) + q];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < GRP; ++j) {
@@ -326,7 +323,7 @@ __device__ __forceinline__ void mlp_value_grad_h2(const S& sys, const MlpP<S::N>
             const f32x2 dv2{dv, dv};
 #pragma unroll
             for (int q = 0; q < NP / 4; ++q) {
-                const float4 w = wbuf[gi & 1][j][q];
+                const float4 w = wbuf[j][q];
                 part[2 * q + 0] = __builtin_elementwise_fma(f32x2{w.x, w.y}, dv2, part[2 * q + 0]);
                 part[2 * q + 1] = __builtin_elementwise_fma(f32x2{w.z, w.w}, dv2, part[2 * q + 1]);
             }

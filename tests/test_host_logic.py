@@ -253,18 +253,26 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_asm_loads
     outs, procs = [], []
-    for act in (0, 1):                                        # one object per activation, compiled side by side
+    for act in (0, 1, 2, 3):                                  # one object per variant (relu, tanh, relu bf16x3, relu f16x2), compiled side by side
         asm = tmp_path / f"mlp_act{act}.s"
         outs.append(asm)
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S",
-                                       "--cuda-device-only", f"-DHJBX_MLP_ACT={act}", "-o", str(asm),
-                                       os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_mlp.hip")], stderr=subprocess.DEVNULL))
+                                       "--cuda-device-only", f"-DHJBX_MLP_ACT={act}"] + (["-fno-slp-vectorize"] if act == 3 else []) +
+                                      ["-o", str(asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_mlp.hip")], stderr=subprocess.DEVNULL))
     for pr in procs:
         assert pr.wait() == 0
     for asm in outs:
         assert audit_asm_loads.audit(str(asm)) == 0
-    text = asm.read_text()
+    text = outs[0].read_text()
     assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
+    # the split-operand kernels run at 243-256 VGPRs: no instantiation may fall back on scratch (a spilled value is reloaded behind an
+    # `s_waitcnt vmcnt(0)` that drains the log stores, and round 2 saw rollout kernels with scratch leave tiles unprocessed)
+    import re
+    for asm, mfma in ((outs[2], "v_mfma_f32_32x32x16_bf16"), (outs[3], "v_mfma_f32_32x32x16_f16")):
+        text = asm.read_text()
+        assert text.count(mfma) >= 30 * 288 and "ds_read_b64_tr_b16" in text
+        scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
+        assert len(scratch) == 30 and max(scratch) == 0, scratch
 
 
 def test_graft_entry_build_check_passes():
