@@ -89,6 +89,45 @@ def test_fused_mfma_value_grad_vs_oracle(name, B, arith):
     assert none is None and torch.equal(g2, g)
 
 
+@pytest.mark.parametrize("case", ["tiny-weights", "huge-weights", "mixed-layers", "outlier-weights", "tiny-states", "far-states", "zero-layer"])
+def test_fused_value_grad_arithmetics_are_scale_free(case, arith):
+    """The 16-bit arithmetics must not care about magnitudes (float16 has a 5-bit exponent: the f16x2 mode scales every weight matrix and every
+    environment's operands by powers of two): weights and states spread over ~60 binades, one matrix with outliers 10^8 above its typical
+    entry, an all-zero layer.  Same bound as test_fused_mfma_value_grad_vs_oracle (2e-5 of the batch scale), every arithmetic."""
+    d, ctl = controller("cartpole", torch.float32)
+    vf = ctl.value_function_approximator
+    B = 3000
+    x = states_near_target(d, ctl, B, 21, 1.5)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    with torch.no_grad():
+        W1, W2, W3 = vf.weights
+        if case == "tiny-weights":
+            W2.mul_(2.0 ** -40); W3.mul_(2.0 ** -30)
+        elif case == "huge-weights":
+            W2.mul_(2.0 ** 30); W3.mul_(2.0 ** 20)
+        elif case == "mixed-layers":
+            W1.mul_(2.0 ** 20); W2.mul_(2.0 ** -45); W3.mul_(2.0 ** 25)
+        elif case == "outlier-weights":                       # 20 entries per matrix 10^8 above the rest
+            for W in (W2, W3):
+                idx = torch.randint(0, W.numel(), (20,), generator=gen, device="cuda")
+                W.view(-1)[idx] *= 1e8
+        elif case == "tiny-states":
+            x = (torch.as_tensor(np.asarray(ctl.xf), device="cuda", dtype=torch.float32) + (x - torch.as_tensor(np.asarray(ctl.xf), device="cuda", dtype=torch.float32)) * 1e-12).contiguous()
+        elif case == "far-states":                            # (not the angle: at 1e6 rad float32 cannot resolve the wrap, in any arithmetic)
+            x = x.clone()
+            x[:, [0, 2, 3]] *= 1e6
+        elif case == "zero-layer":
+            W3.zero_()
+    V, g = vf.fused_value_grad(x)
+    assert torch.isfinite(V).all() and torch.isfinite(g).all()
+    mlp, W = oracle_mlp(ctl)
+    oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
+    sv, sg = max(np.abs(oV).max(), 1e-300), max(np.abs(og).max(), 1e-300)
+    eV, eg = np.abs(V.cpu().numpy() - oV).max() / sv, np.abs(g.cpu().numpy() - og).max() / sg
+    print(f"\n{case} [{arith}]: |V| up to {sv:.2e} (max err / scale {eV:.1e}), |gradV| up to {sg:.2e} ({eg:.1e})")
+    assert eV <= 2e-5 and eg <= 2e-5
+
+
 def test_fused_value_grad_quadratic_known_answer():
     """load_quadratic(P): V = e'Pe + eps|e|^2 and grad = 2(P + eps I)e exactly (up to f32 rounding)."""
     d, ctl = controller("quad2d")
