@@ -340,12 +340,13 @@ def param_gradient_kernels(system="nearhover", B=1 << 20):
                 scratch_bytes_per_sample=2 * 4.0 * 40960 / 32)
 
 
-def optimiser_step(world, dist):
-    """params_update (reference controller/vhjb.py:255-288) at the reference's minibatch of 256 samples IN TOTAL (256 / G per rank):
-    updates per second including, for G > 1, the flat gradient all-reduce (RCCL)."""
-    wl = make_workload("cartpole", "euler", "relu", 4096, 11)
+def optimiser_step(world, dist, system="cartpole", total=256):
+    """params_update (reference controller/vhjb.py:255-288) on `total` samples IN TOTAL (total / G per rank; 256 = the reference's
+    minibatch; 2^20 per GPU = the sharded training step of BASELINE configs[4]): updates per second including, for G > 1, the flat
+    gradient all-reduce (RCCL)."""
+    wl = make_workload(system, "euler", "relu", max(4096, total // world), 11)
     ctl = wl["ctl"]
-    per_rank = max(1, 256 // world)
+    per_rank = max(1, total // world)
     gen = torch.Generator(device="cuda").manual_seed(5)
     xs = wl["x0"][:per_rank].contiguous()
     dones = (torch.rand(per_rank, generator=gen, device="cuda") < 0.1).float()
@@ -357,17 +358,39 @@ def optimiser_step(world, dist):
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    R = 100
+    R = 100 if per_rank <= 65536 else 20
     for _ in range(R):
         update(xs, dones, costs, 1e-5)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    return dict(name="params_update (cartpole, minibatch 256 in total)", ranks=world, samples_per_rank=per_rank, updates_per_s=R / dt,
+    return dict(name=f"params_update ({system}, {total} samples in total)", ranks=world, samples_per_rank=per_rank, updates_per_s=R / dt,
                 samples_per_s=R * per_rank * world / dt, ms_per_update=dt / R * 1e3,
                 gradient=("fused MFMA kernels (hjbx_value_loss_grad_f32)" if ctl.fused_param_grad else "PyTorch autograd"),
                 mode=("hipGraph replay" if ctl.graph_updates else "eager launches" + (" + one flat all-reduce" if world > 1 else "")))
+
+
+def parity_evidence(arith, system):
+    """What the GPU parity tests measured for this arithmetic (tests/test_gpu_f32_parity.py writes the report; the committed copy is
+    profiles/r02_f32_parity_report.json): per-element errors of one teacher-forced step at full batch against the f64 oracle, as a
+    fraction of the 1e-5 bound, next to the same numbers of the bitwise-f32 MFMA kernel.  Static data, not re-measured by the bench."""
+    path = os.path.join(ROOT, "profiles", "r02_f32_parity_report.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rep = json.load(f)
+    out = dict(source="profiles/r02_f32_parity_report.json (tests/test_gpu_f32_parity.py, full batch, f64 oracle)", tolerance="|err| <= 1e-5 |want| + 1e-5 x (sum of the element's |terms|)")
+    for a in dict.fromkeys((arith, "f32")):
+        rows = {k.split("/")[3]: v for k, v in rep.items() if k.startswith(f"teacher_forced/{a}/{system}/")}
+        if rows:
+            out[a] = {w: dict(max_err_over_bound={q: r[q]["max_ratio"] for q in ("x_next", "u", "cost", "residual")},
+                              max_abs_err={q: r[q]["max_err"] for q in ("x_next", "u", "cost", "residual")}, at_relu_kink_not_compared=r["at_kink_fraction"])
+                      for w, r in rows.items()}
+        ds = rep.get(f"done_step/{a}/{system}")
+        if ds:
+            out[a]["done_step_30_steps"] = {k: ds[k] for k in ("mismatches_in_safe", "mismatches_in_safe_at_relu_kinks", "mismatches_in_band", "filtered_fraction") if k in ds}
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -508,10 +531,18 @@ def main():
             sec.append(param_gradient_kernels("nearhover", 1 << 20))
             torch.cuda.empty_cache()
         sec_opt = optimiser_step(world, dist)                  # every rank takes part (all-reduce inside for G > 1)
+        sec_big = optimiser_step(world, dist, "nearhover", (1 << 20) * world)     # configs[4]: the sharded full-batch learning step
         if rank == 0:
-            sec.append(sec_opt)
+            sec += [sec_opt, sec_big]
             out["secondary"] = sec
 
+    if rank == 0:
+        out["config"]["value_network_arithmetic"] = {
+            "f32": "f32 MFMA (bitwise an fmaf chain)",
+            "bf16x3": "float32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 MFMA, f32 accumulation",
+            "f16x2": "float32 operands scaled per environment by a power of two and rounded to 2 f16 pieces (22 significant bits), 3 piece products "
+                     "on the f16 MFMA, f32 accumulation; inputs, outputs, layer 1, dynamics and costs are float32"}[args.arithmetic]
+        out["parity_evidence"] = parity_evidence(args.arithmetic, args.system)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the host-core baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(dyn, ctl, wl["x0"], args.cpu_sample_envs)
     if rank == 0:
