@@ -49,17 +49,14 @@ template <int N> struct MlpLdsH2 {
 __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
 }
-// x s - (f16 half HALF of pk), one v_fma_mix_f32 (the product with the power of two s and the difference are exact)
-template <int HALF> __device__ __forceinline__ float scaled_residual(float x, float s, uint32_t pk) {
-    float r;
-    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(pk));
-    else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(pk));
-    return r;
-}
-// pieces of the pair (x0 s, x1 s): packed {x0 piece, x1 piece}
+// pieces of the pair (x0 s, x1 s): packed {x0 piece, x1 piece}.  The products with the power of two s and the residuals are exact.
+// Six instructions (2 v_mul, v_cvt_pk_f16_f32, 2 v_fma_mix_f32, v_cvt_pk_f16_f32).  Measured alternatives, cartpole B = 2^20: the same with
+// the v_fma_mix as inline asm 0.2662 ms / step (this: 0.2625); v_cvt_f32_f16 + v_fma_f32 instead of each v_fma_mix 0.2676; four
+// instructions with v_fma_mixlo_f16 / v_fma_mixhi_f16 (fma and round to float16 in one) 0.2839 -- fewer but slower instructions.
 __device__ __forceinline__ void h2_split_pair(float x0, float x1, float s, uint32_t& hi, uint32_t& lo) {
     hi = cvt_pk_f16(x0 * s, x1 * s);
-    lo = cvt_pk_f16(scaled_residual<0>(x0, s, hi), scaled_residual<1>(x1, s, hi));
+    const f16x2 h = __builtin_bit_cast(f16x2, hi);
+    lo = cvt_pk_f16(__builtin_fmaf(x0, s, -(float)h[0]), __builtin_fmaf(x1, s, -(float)h[1]));   // hipcc: one v_fma_mix_f32 each
 }
 
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (uint32_t)(127 + k) << 23); }  // -126 <= k <= 127
