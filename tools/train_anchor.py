@@ -29,7 +29,12 @@ def main():
                     "drone_hovering.ipynb cell 10): data set seeded with 256 copies of xf, no boundary set, no termination loss")
     ap.add_argument("--warm_start", type=int, default=0, help="seed the replay buffer with this many closed loops of the model-based "
                     "controller first (BASELINE configs[2]: acrobot energy-shaping warm-start + vhjb)")
+    ap.add_argument("--arithmetic", default=None, choices=["f32", "bf16x3", "f16x2"], help="value-network arithmetic of the fused kernels "
+                    "(HJBX_OPT_MLP_ARITHMETIC; default: the library's = f16x2)")
     args = ap.parse_args()
+    if args.arithmetic:
+        from q_learning_with_hjb_amd import _abi
+        _abi.set_option(_abi.OPT_MLP_ARITHMETIC, {"f32": 0, "bf16x3": 1, "f16x2": 2}[args.arithmetic])
     over = {}
     if args.notebook:
         over = dict(num_of_interior_data=256, num_of_boundary_data=0, regularization_peak_value=0.0, regularization_init_value=0.0,
@@ -48,11 +53,21 @@ def main():
     np.random.seed(123)
     res = test_policy(pol, dyn, mb, T=args.T, batch=args.starts)
     cl, cm = res["cost_learned"].sum(0), res["cost_model_based"].sum(0)
-    print(json.dumps(dict(env=args.env, seed=args.seed, activation=args.activation, notebook=args.notebook, epochs=args.epochs,
+    # the same trained network evaluated in every value-network arithmetic (same start states)
+    from q_learning_with_hjb_amd import _abi as _A
+    prev = _A.set_option(_A.OPT_MLP_ARITHMETIC, -1)
+    cost_by_arithmetic = {}
+    if args.activation == "relu":
+        for nm, v in (("f32", 0), ("bf16x3", 1), ("f16x2", 2)):
+            _A.set_option(_A.OPT_MLP_ARITHMETIC, v)
+            np.random.seed(123)
+            cost_by_arithmetic[nm] = float(test_policy(pol, dyn, mb, T=args.T, batch=args.starts)["cost_learned"].sum(0).mean())
+        _A.set_option(_A.OPT_MLP_ARITHMETIC, prev)
+    print(json.dumps(dict(env=args.env, seed=args.seed, arithmetic=args.arithmetic or "f16x2", activation=args.activation, notebook=args.notebook, epochs=args.epochs,
                           warm_start=None if ws is None else dict(records=ws["records"], average_trajectory_cost=round(ws["average_trajectory_cost"], 2)), updates=pol.update_counter, train_seconds=round(train_s, 1),
                           replay_records=len(pol.replay_buffer), avg_traj_len_first=lists[2][0], avg_traj_len_last=lists[2][-1],
                           hjb_loss_first=lists[4][0] if lists[4] else None, hjb_loss_last=lists[4][-1] if lists[4] else None,
-                          mean_cost_learned=float(cl.mean()), mean_cost_model_based=float(cm.mean()),
+                          mean_cost_learned=float(cl.mean()), mean_cost_model_based=float(cm.mean()), mean_cost_learned_by_eval_arithmetic=cost_by_arithmetic,
                           per_start_learned=[round(float(v), 3) for v in cl], per_start_model_based=[round(float(v), 3) for v in cm])))
 
 
