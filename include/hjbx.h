@@ -100,7 +100,8 @@ typedef enum hjbx_option {
                                               others finish -- the situation the take-over above exists for); default 0 */
     HJBX_OPT_STREAM_ROWS = 2,              /* TUNING: rows per thread of the float32 streaming kernels (simulate, vhjb_step, hjb_residual):
                                               1, 2 or 4; 0 (default) = the library's choice */
-    HJBX_OPT_MLP_ARITHMETIC = 3            /* arithmetic of the ReLU value network inside hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 (THE ONE KNOB
+    HJBX_OPT_MLP_ARITHMETIC = 3            /* arithmetic of the ReLU value network inside hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 and of the eight
+                                              128 / 64-wide products of hjbx_value_loss_grad_f32 (mode 1 runs those on the f32 MFMA) (THE ONE KNOB
                                               THAT CHANGES RESULTS, within float32 rounding; inputs, outputs, accumulation, layer 1 and everything
                                               outside the network are float32 in every mode; tanh networks always run mode 0):
                                               0 = float32 MFMA, bitwise an fmaf chain (the slowest: 1 / 16 of the 16-bit matrix rate);

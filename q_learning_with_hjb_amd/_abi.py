@@ -35,7 +35,7 @@ _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=2",), "hjbx_mlp_x3.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=3", "-fno-slp-vectorize"), "hjbx_mlp_h2.o"),
-          ("hjbx_train.hip", (), "hjbx_train.o"))
+          ("hjbx_train.hip", ("-fno-slp-vectorize",), "hjbx_train.o"))
 _SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
 _HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", "hjbx_mlp_x3.hpp", "hjbx_mlp_h2.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 

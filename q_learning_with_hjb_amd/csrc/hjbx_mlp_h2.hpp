@@ -183,23 +183,23 @@ __device__ __forceinline__ void h2_split(const f32x16 (&in)[NIN], float s, uint3
 // from the CU's LDS a read took longer than the two units of the first version to come back (SQ_WAIT_INST_ANY: 48 % of the wave cycles).
 static constexpr int kH2Depth = 3;   // x 4 reads per unit <= 15 (lgkmcnt is a 4-bit counter)
 
-template <typename Dir, int NK, int NOUT, int NIN, int PRE, int U>
-__device__ __forceinline__ void h2_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], uint32_t base, float s, H2Ops (&ring)[kH2Depth + 1],
+template <typename Dir, int NK, int NOUT, int NIN, int PRE, int DEPTH, int U>
+__device__ __forceinline__ void h2_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], uint32_t base, float s, H2Ops (&ring)[DEPTH + 1],
                                         uint32_t (&Bp)[2][2][4], uint32_t& root, uint32_t (&m)[2]) {
     constexpr int NU = NK * NOUT;
     if constexpr (U < NU) {
         constexpr int K = U / NOUT, O = U % NOUT;
-        if constexpr (U + kH2Depth < NU)
-            h2_issue<Dir, (U + kH2Depth) / NOUT, (U + kH2Depth) % NOUT>(ring[(U + kH2Depth) % (kH2Depth + 1)], base, root);
+        if constexpr (U + DEPTH < NU)
+            h2_issue<Dir, (U + DEPTH) / NOUT, (U + DEPTH) % NOUT>(ring[(U + DEPTH) % (DEPTH + 1)], base, root);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (K + 1 < NK) {
             constexpr int PP = 4 / NOUT;
             h2_split<NIN, K + 1, O * PP, PRE>(in, s, Bp[(K + 1) & 1], m);
             if constexpr (PP == 2) h2_split<NIN, K + 1, O * PP + 1, PRE>(in, s, Bp[(K + 1) & 1], m);
         }
-        constexpr int ahead = (NU - 1 - U < kH2Depth ? NU - 1 - U : kH2Depth) * 4;
+        constexpr int ahead = (NU - 1 - U < DEPTH ? NU - 1 - U : DEPTH) * 4;
         lds_wait<ahead>();
-        const H2Ops& o = ring[U % (kH2Depth + 1)];
+        const H2Ops& o = ring[U % (DEPTH + 1)];
         const u32x4 ah{o.r[0][0][0], o.r[0][0][1], o.r[0][1][0], o.r[0][1][1]};
         const u32x4 al{o.r[1][0][0], o.r[1][0][1], o.r[1][1][0], o.r[1][1][1]};
         const uint32_t(&B)[2][4] = Bp[K & 1];
@@ -210,7 +210,7 @@ __device__ __forceinline__ void h2_unit(f32x16 (&out)[NOUT], const f32x16 (&in)[
         acc = MFMA_F16(ah, bh, acc);
         out[O] = acc;
         __builtin_amdgcn_sched_barrier(0);
-        h2_unit<Dir, NK, NOUT, NIN, PRE, U + 1>(out, in, base, s, ring, Bp, root, m);
+        h2_unit<Dir, NK, NOUT, NIN, PRE, DEPTH, U + 1>(out, in, base, s, ring, Bp, root, m);
     }
 }
 
@@ -224,25 +224,27 @@ template <int NIN, bool RELU> __device__ __forceinline__ float h2_absmax(const f
     return fmaxf(mx, __shfl_xor(mx, 32, 64));
 }
 
-// out[o] = 2^(k + kw) x (W-image product of PRE(in)); returns k (the caller adds k + kw to the lane's exponent)
-template <typename Dir, int NOUT, int NIN, int PRE>
+// out[o] = 2^(k + kw) x (W-image product of PRE(in)); returns k (the caller adds k + kw to the lane's exponent).  DEPTH: how many units
+// ahead the LDS reads run (8 registers each; the training kernel, tighter on registers, uses 2)
+template <typename Dir, int NOUT, int NIN, int PRE, int DEPTH = kH2Depth>
 __device__ __forceinline__ int h2_chain(f32x16 (&out)[NOUT], const f32x16 (&in)[NIN], uint32_t base, uint32_t (&m)[2]) {
     constexpr int NK = 2 * NIN;
     static_assert(NOUT == 2 || NOUT == 4, "");
     const int k = scale_exponent<14>(h2_absmax<NIN, PRE == kPreReluMask>(in));
     const float s = pow2f(k);
-    H2Ops ring[kH2Depth + 1];
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "");
+    H2Ops ring[DEPTH + 1];
     uint32_t Bp[2][2][4];
     uint32_t root;
     h2_issue<Dir, 0, 0>(ring[0], base, root);
-    h2_issue<Dir, 1 / NOUT, 1 % NOUT>(ring[1], base, root);
-    if constexpr (kH2Depth > 2) h2_issue<Dir, 2 / NOUT, 2 % NOUT>(ring[2], base, root);
+    if constexpr (DEPTH > 1) h2_issue<Dir, 1 / NOUT, 1 % NOUT>(ring[1], base, root);
+    if constexpr (DEPTH > 2) h2_issue<Dir, 2 / NOUT, 2 % NOUT>(ring[2], base, root);
     __builtin_amdgcn_sched_barrier(0);
     h2_split<NIN, 0, 0, PRE>(in, s, Bp[0], m);
     h2_split<NIN, 0, 1, PRE>(in, s, Bp[0], m);
     h2_split<NIN, 0, 2, PRE>(in, s, Bp[0], m);
     h2_split<NIN, 0, 3, PRE>(in, s, Bp[0], m);
-    h2_unit<Dir, NK, NOUT, NIN, PRE, 0>(out, in, base, s, ring, Bp, root, m);
+    h2_unit<Dir, NK, NOUT, NIN, PRE, DEPTH, 0>(out, in, base, s, ring, Bp, root, m);
     mfma_results_barrier<8>();
     return k;
 }

@@ -1,5 +1,5 @@
-// hjbx_train.hip -- the parameter gradient of the value-learning step (reference controller/vhjb.py:227-253, 282-284) on the f32
-// matrix cores: d(sum_b hjb_loss_b)/dW and d(sum_b termination_loss_b)/dW for W1, W2, W3 of the 3-layer value network, plus the loss
+// hjbx_train.hip -- the parameter gradient of the value-learning step (reference controller/vhjb.py:227-253, 282-284) on the
+// matrix cores (chains: f16x2 split-operand products by default, f32 MFMA on request; outer products: f32 MFMA): d(sum_b hjb_loss_b)/dW and d(sum_b termination_loss_b)/dW for W1, W2, W3 of the 3-layer value network, plus the loss
 // sums and the two counts, for a batch of B samples (x, cost, done).  hjb_loss depends on the weights through dV/dx, so its
 // parameter gradient is a second-order reverse sweep ("double back-prop": jax.grad of a function of jax.grad in the reference).
 //
@@ -31,6 +31,7 @@
 #include "hjbx_systems.hpp"
 #include "hjbx_host.hpp"
 #include "hjbx_mlp_core.hpp"
+#include "hjbx_mlp_h2.hpp"
 
 using namespace hjbx;
 
@@ -66,7 +67,8 @@ __device__ __forceinline__ LaneSlots lane_slots(int e, int hh) {
         l.off[q] = (uint32_t)(((e >> 4) * kImgFloats + (q * 2 + hh) * kImgGroup + (((e & 15) ^ (2 * q + hh)) * 4)) * sizeof(float));
     return l;
 }
-template <int NB> __device__ __forceinline__ void store_tile_array(float* __restrict__ tile, int a, const f32x16 (&v)[NB], const LaneSlots& ls) {
+// `sc`: what the values are multiplied with on their way out (a power of two: the f16x2 chains keep their accumulators scaled, 1 otherwise)
+template <int NB> __device__ __forceinline__ void store_tile_array(float* __restrict__ tile, int a, const f32x16 (&v)[NB], const LaneSlots& ls, float sc = 1.0f) {
 #pragma unroll
     for (int fb = 0; fb < NB; ++fb) {
         uint32_t boff = (uint32_t)((group0(a) + fb * 8) * kImgGroup * sizeof(float));
@@ -74,7 +76,7 @@ template <int NB> __device__ __forceinline__ void store_tile_array(float* __rest
         char* blk = reinterpret_cast<char*>(tile) + boff;                               // wave uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(blk + ls.off[q]) = make_float4(v[fb][4 * q], v[fb][4 * q + 1], v[fb][4 * q + 2], v[fb][4 * q + 3]);
+            *reinterpret_cast<float4*>(blk + ls.off[q]) = make_float4(v[fb][4 * q] * sc, v[fb][4 * q + 1] * sc, v[fb][4 * q + 2] * sc, v[fb][4 * q + 3] * sc);
     }
 }
 
@@ -109,14 +111,25 @@ __device__ __forceinline__ void relu_mask_apply(f32x16 (&v)[4], const uint32_t (
         }
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
+// Sum over the wave, result in lane 0 (a fixed shuffle tree: deterministic).  `self` is the lane index, rebuilt by the caller at the END of
+// the kernel behind an opaque asm: __shfl_down's own __lane_id() is CSE'd with the one from the top of the kernel, and keeping that value (or
+// its `<< 2` / `<< 3` address forms) alive through the whole tile loop was the one register hipcc spilled in the f16x2 instantiations.
+__device__ __forceinline__ double wave_sum_d(double v, int self) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        const int idx = ((self + off) & 63) << 2;   // lanes >= 64 - off read wrapped lanes: never on lane 0's path
+        const uint64_t b = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)(uint32_t)(b >> 32));
+        v += __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    }
     return v;
 }
 
 // ---- kernel 1: all matrix-vector chains of one tile per wave --------------------------------------------------------------
-template <int MODE, typename S, int WAVES>
+// H2: the eight 128 / 64-wide products as f16x2 split-operand chains (hjbx_mlp_h2.hpp; HJBX_OPT_MLP_ARITHMETIC = 2) instead of f32 MFMA chains.
+// Element-wise passes and masks work on the scaled accumulators (ReLU and its mask do not care about a positive factor); every array is
+// multiplied by 2^-E of its lane (environment) when it is written to the scratch, so k_train_outer sees true values.
+template <int MODE, typename S, int WAVES, bool H2>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k,
                                                                       Limits<float, S::M> lim_k, const float* __restrict__ W1g,
                                                                       const float* __restrict__ W2g, const float* __restrict__ W3g,
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
     constexpr int N = S::N, M = S::M, ACT = HJBX_ACT_RELU;
     constexpr int NP = MlpLds<N>::NP;
     static_assert(N % 2 == 0 && N <= 32, "state dimension");
-    __shared__ __attribute__((aligned(16))) MlpLds<N> L;
+    __shared__ __attribute__((aligned(256))) std::conditional_t<H2, MlpLdsH2<N>, MlpLds<N>> L;
     __shared__ __attribute__((aligned(16))) unsigned char sys_raw[sizeof(S)];
     S& sys_s = *reinterpret_cast<S*>(sys_raw);
     __shared__ MlpP<N> p_s;
@@ -135,16 +148,41 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
     __shared__ double red[4][WAVES];
     const int tid = threadIdx.x;
     if (tid == 0) { sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k; }
-    mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    if constexpr (H2) mlp_fill_lds_h2<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
+    else mlp_fill_lds<N, WAVES * 64>(L, W1g, W2g, W3g, tid);
     __syncthreads();
     const S& sys = sys_s;
     const MlpP<N>& p = p_s;
     const TaskP<float, N, M>& tk = tk_s;
     const Limits<float, M>& lim = lim_s;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: tile pointers stay wave uniform (saddr stores)
-    const MlpCtx c = mlp_ctx<N>(L, lane);
+    const auto c = [&] {
+        if constexpr (H2) return mlp_ctx_h2<N>(L, lane);
+        else return mlp_ctx<N>(L, lane);
+    }();
     const int i = c.i, h = c.h;
     double acc_h = 0, acc_t = 0, acc_ni = 0, acc_nd = 0;
+    // the four big products; each returns the exponent its result carries on top of its input's (0 for the f32 chains).  LDS reads run two
+    // units ahead of their MFMAs (one for n = 6, whose instantiations were a register over: a spill is not an option here)
+    constexpr int kDepth = N == 6 ? 1 : 2;
+    uint32_t m0[2] = {0u, 0u};
+    auto prod_w2f = [&](f32x16 (&out)[4], const f32x16 (&in)[4], float (&ring)[3][4]) -> int {
+        if constexpr (H2) return h2_chain<H2Fwd, 4, 4, kPreNone, kDepth>(out, in, c.f2, m0) + c.kw2;
+        else { f32x16 (&o1)[1][4] = reinterpret_cast<f32x16 (&)[1][4]>(out); mfma_chain<OffW2F, 64, 4, 2, 1>(o1, ring, c.w2f, [&](int st, int) { return in[st >> 4][st & 15]; }); return 0; }
+    };
+    auto prod_w3f = [&](f32x16 (&out)[2], const f32x16 (&in)[4], float (&ring)[3][2]) -> int {
+        if constexpr (H2) return h2_chain<H2Fwd, 2, 4, kPreNone, kDepth>(out, in, c.f3, m0) + c.kw3;
+        else { f32x16 (&o1)[1][2] = reinterpret_cast<f32x16 (&)[1][2]>(out); mfma_chain<OffW3F, 64, 2, 2, 1>(o1, ring, c.w3f, [&](int st, int) { return in[st >> 4][st & 15]; }); return 0; }
+    };
+    auto prod_w3b = [&](f32x16 (&out)[4], const f32x16 (&in)[2], float (&ring)[3][4]) -> int {
+        if constexpr (H2) return h2_chain<H2Bwd, 4, 2, kPreNone, kDepth>(out, in, c.t3, m0) + c.kw3;
+        else { f32x16 (&o1)[1][4] = reinterpret_cast<f32x16 (&)[1][4]>(out); mfma_chain<OffW3B, 32, 4, 2, 1>(o1, ring, c.w3b, [&](int st, int) { return in[st >> 4][st & 15]; }); return 0; }
+    };
+    auto prod_w2b = [&](f32x16 (&out)[4], const f32x16 (&in)[4], float (&ring)[3][4]) -> int {
+        if constexpr (H2) return h2_chain<H2Bwd, 4, 4, kPreNone, kDepth>(out, in, c.t2, m0) + c.kw2;
+        else { f32x16 (&o1)[1][4] = reinterpret_cast<f32x16 (&)[1][4]>(out); mfma_chain<OffW2B, 64, 4, 2, 1>(o1, ring, c.w2b, [&](int st, int) { return in[st >> 4][st & 15]; }); return 0; }
+    };
+    auto unscale = [](int E) { return __builtin_amdgcn_ldexpf(1.0f, -E); };
     const LaneSlots ls = lane_slots(i, h);
     // tiles are dealt wave-major over the workgroups (tile = (wave + WAVES k) gridDim + block): a small batch spreads one wave per CU
     // inputs of a tile are fetched while the previous tile is in flight (after its residual): vmcnt retires in order, so a load issued
@@ -197,16 +235,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
         store_tile_array<4>(tb, A_H1, a1[0], ls);
         f32x16 a2[1][4];
         zero_acc(a2);
-        mfma_chain<OffW2F, 64, 4, 2, 1>(a2, ring4, c.w2f, [&](int st, int) { return a1[0][st >> 4][st & 15]; });
+        int E = prod_w2f(a2[0], a1[0], ring4);     // (E: the exponent the current accumulators carry, per environment)
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[0][fb][r] = act1<ACT>(a2[0][fb][r]);
         relu_mask_build(a2[0], m2);
-        store_tile_array<4>(tb, A_H2, a2[0], ls);
+        store_tile_array<4>(tb, A_H2, a2[0], ls, unscale(E));
         f32x16 y[1][2];
         zero_acc(y);
-        mfma_chain<OffW3F, 64, 2, 2, 1>(y, ring2, c.w3f, [&](int st, int) { return a2[0][st >> 4][st & 15]; });
+        E += prod_w3f(y[0], a2[0], ring2);
         float vpart = 0.f;
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
@@ -215,20 +253,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
                 vpart += y[0][ob][r] * y[0][ob][r];
                 y[0][ob][r] += y[0][ob][r];   // dy = 2y
             }
-        const float V = vpart + __shfl_xor(vpart, 32, 64) + p.eps_s * ee;
-        store_tile_array<2>(tb, A_DY, y[0], ls);
+        const float V = __builtin_amdgcn_ldexpf(vpart + __shfl_xor(vpart, 32, 64), -2 * E) + p.eps_s * ee;
+        store_tile_array<2>(tb, A_DY, y[0], ls, unscale(E));
 
         // ---- input gradient ------------------------------------------------------------------------------------------
         f32x16 d2[1][4];
         zero_acc(d2);
-        mfma_chain<OffW3B, 32, 4, 2, 1>(d2, ring4, c.w3b, [&](int st, int) { return y[0][st >> 4][st & 15]; });
+        E += prod_w3b(d2[0], y[0], ring4);
         relu_mask_apply(d2[0], m2);
-        store_tile_array<4>(tb, A_D2, d2[0], ls);
+        store_tile_array<4>(tb, A_D2, d2[0], ls, unscale(E));
         f32x16 d1[1][4];
         zero_acc(d1);
-        mfma_chain<OffW2B, 64, 4, 2, 1>(d1, ring4, c.w2b, [&](int st, int) { return d2[0][st >> 4][st & 15]; });
+        E += prod_w2b(d1[0], d2[0], ring4);
         relu_mask_apply(d1[0], m1);
-        store_tile_array<4>(tb, A_D1, d1[0], ls);
+        const float un1 = unscale(E);
+        store_tile_array<4>(tb, A_D1, d1[0], ls, un1);
         float g[N];
         {
             f32x2 part[NP / 2];
@@ -250,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const float pk = part[k >> 1][k & 1];
-                g[k] = (pk + __shfl_xor(pk, 32, 64)) * p.istd[k] + 2.f * p.eps_s * e[k];
+                g[k] = (pk + __shfl_xor(pk, 32, 64)) * un1 * p.istd[k] + 2.f * p.eps_s * e[k];
             }
         }
 
@@ -293,37 +332,39 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_train_chains(S sys_k,
         store_tile_array<4>(tb, A_DH1B, t1[0], ls);
         f32x16 t2[1][4];
         zero_acc(t2);
-        mfma_chain<OffW2F, 64, 4, 2, 1>(t2, ring4, c.w2f, [&](int st, int) { return t1[0][st >> 4][st & 15]; });
+        E = prod_w2f(t2[0], t1[0], ring4);
         relu_mask_apply(t2[0], m2);
-        store_tile_array<4>(tb, A_DH2B, t2[0], ls);
+        store_tile_array<4>(tb, A_DH2B, t2[0], ls, unscale(E));
         f32x16 t3[1][2];
         zero_acc(t3);
-        mfma_chain<OffW3F, 64, 2, 2, 1>(t3, ring2, c.w3f, [&](int st, int) { return t2[0][st >> 4][st & 15]; });
+        E += prod_w3f(t3[0], t2[0], ring2);
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) t3[0][ob][rr] += t3[0][ob][rr];   // yb = 2 W3' dh2b
-        store_tile_array<2>(tb, A_YB, t3[0], ls);
+        store_tile_array<2>(tb, A_YB, t3[0], ls, unscale(E));
         f32x16 t4[1][4];
         zero_acc(t4);
-        mfma_chain<OffW3B, 32, 4, 2, 1>(t4, ring4, c.w3b, [&](int st, int) { return t3[0][st >> 4][st & 15]; });
+        E += prod_w3b(t4[0], t3[0], ring4);
         relu_mask_apply(t4[0], m2);
-        store_tile_array<4>(tb, A_A2B, t4[0], ls);
+        store_tile_array<4>(tb, A_A2B, t4[0], ls, unscale(E));
         f32x16 t5[1][4];
         zero_acc(t5);
-        mfma_chain<OffW2B, 64, 4, 2, 1>(t5, ring4, c.w2b, [&](int st, int) { return t4[0][st >> 4][st & 15]; });
+        E += prod_w2b(t5[0], t4[0], ring4);
         relu_mask_apply(t5[0], m1);
-        store_tile_array<4>(tb, A_A1B, t5[0], ls);
+        store_tile_array<4>(tb, A_A1B, t5[0], ls, unscale(E));
     }
     // loss sums and counts of this workgroup: lanes -> wave (shuffle tree) -> LDS -> one record (fixed order: deterministic)
-    acc_h = wave_sum_d(acc_h); acc_t = wave_sum_d(acc_t); acc_ni = wave_sum_d(acc_ni); acc_nd = wave_sum_d(acc_nd);
-    if (lane == 0) { red[0][wave] = acc_h; red[1][wave] = acc_t; red[2][wave] = acc_ni; red[3][wave] = acc_nd; }
+    int l4;   // the lane index, rebuilt here (see wave_sum_d)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l4));
+    acc_h = wave_sum_d(acc_h, l4); acc_t = wave_sum_d(acc_t, l4); acc_ni = wave_sum_d(acc_ni, l4); acc_nd = wave_sum_d(acc_nd, l4);
+    if (l4 == 0) { red[0][wave] = acc_h; red[1][wave] = acc_t; red[2][wave] = acc_ni; red[3][wave] = acc_nd; }
     __syncthreads();
-    if (tid < 4) {
+    if (wave == 0 && l4 < 4) {
         double s = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) s += red[tid][w];
-        sums_rec[4 * (int64_t)blockIdx.x + tid] = s;
+        for (int w = 0; w < WAVES; ++w) s += red[l4][w];
+        sums_rec[4 * (int64_t)blockIdx.x + l4] = s;
     }
 }
 
@@ -574,12 +615,20 @@ static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, c
         const int gridB = gridA;
         const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
         hipStream_t s = (hipStream_t)st;
-        if (mode == HJBX_RESIDUAL_NORMALISED)
-            hipLaunchKernelGGL((k_train_chains<0, S, kTrWaves>), dim3(gridA), dim3(kTrWaves * 64), 0, s, sys, p, tk, lim, W1, W2, W3, x, cost, done,
-                               (float)task->eps, scratch, sums, B, w.ntiles);
-        else
-            hipLaunchKernelGGL((k_train_chains<1, S, kTrWaves>), dim3(gridA), dim3(kTrWaves * 64), 0, s, sys, p, tk, lim, W1, W2, W3, x, cost, done,
-                               (float)task->eps, scratch, sums, B, w.ntiles);
+        // the chains in the library's value-network arithmetic (HJBX_OPT_MLP_ARITHMETIC): f16x2 split-operand products, or the f32 MFMA for
+        // modes 0 (f32) and 1 (bf16x3 has no training instantiation)
+        auto chains = [&](auto mode_c, auto h2_c) {
+            hipLaunchKernelGGL((k_train_chains<decltype(mode_c)::value, S, kTrWaves, decltype(h2_c)::value>), dim3(gridA), dim3(kTrWaves * 64), 0, s, sys, p, tk, lim,
+                               W1, W2, W3, x, cost, done, (float)task->eps, scratch, sums, B, w.ntiles);
+        };
+        const bool h2 = hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 2;
+        if (mode == HJBX_RESIDUAL_NORMALISED) {
+            if (h2) chains(std::integral_constant<int, 0>{}, std::true_type{});
+            else chains(std::integral_constant<int, 0>{}, std::false_type{});
+        } else {
+            if (h2) chains(std::integral_constant<int, 1>{}, std::true_type{});
+            else chains(std::integral_constant<int, 1>{}, std::false_type{});
+        }
         static bool attr_set = false;   // 160 KiB of dynamic LDS need the opt-in once per kernel
         const size_t lds_bytes = 2 * (size_t)kImgFloats * sizeof(float);
         if (!attr_set) {

@@ -59,7 +59,7 @@ def _unpack(flat, n):
 
 @pytest.mark.parametrize("B", [1, 33, 256, 1000])
 @pytest.mark.parametrize("name", SYSTEMS)
-def test_value_loss_grad_vs_f64_autograd(name, B):
+def test_value_loss_grad_vs_f64_autograd(name, B, arith):
     """float32 MFMA kernels vs float64 autograd double back-prop: every gradient matrix to 1e-4 of its largest entry (per element) and
     1e-4 in the Frobenius norm; loss sums to 1e-5; counts exact.  B = 1 / 33 / 1000 exercise padding lanes and partial tiles."""
     d, ctl = controller(name)
@@ -87,7 +87,7 @@ def test_value_loss_grad_vs_f64_autograd(name, B):
 
 
 @pytest.mark.parametrize("name", ["cartpole", "quad2d"])
-def test_value_loss_grad_raw_residual_mode(name):
+def test_value_loss_grad_raw_residual_mode(name, arith):
     """HJBX_RESIDUAL_RAW (|gradV.xdot + l|, examples/cartpole_balancing.ipynb cell 11) against autograd through the f64 HIP residual op."""
     d, ctl = controller(name, residual_mode=_abi.RESIDUAL_RAW)
     vf = ctl.value_function_approximator
@@ -101,7 +101,7 @@ def test_value_loss_grad_raw_residual_mode(name):
         assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-30)
 
 
-def test_value_loss_grad_properties_at_scale():
+def test_value_loss_grad_properties_at_scale(arith):
     """B = 2^17 + 77 (more tiles than workgroups, ragged tail): (a) bitwise reproducible, (b) additive over a split of the batch,
     (c) samples marked done contribute nothing to the hjb set and only they contribute to the termination set."""
     d, ctl = controller("cartpole")
