@@ -337,7 +337,10 @@ def param_gradient_kernels(system="nearhover", B=1 << 20):
     ach = flops * B / t / 1e12
     return dict(name=f"value_loss_grad: parameter gradient of the learning step ({system}, B=2^{int(np.log2(B))})", ms=t * 1e3, samples_per_s=B / t,
                 achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TFLOPS, bound="mfma", flop_per_sample=flops,
-                scratch_bytes_per_sample=2 * 4.0 * 40960 / 32)
+                scratch_bytes_per_sample=2 * 4.0 * 40960 / 32,
+                note="achieved = ALGORITHMIC float32 flops per second; the outer-product kernel runs them on the f32 MFMA, the chains kernel runs its "
+                     "eight wide products as f16x2 split-operand chains on the f16 MFMA in the default arithmetic (3 piece products each), so frac is a "
+                     "float32-equivalent rate against the f32 MFMA peak, not the occupancy of one pipe")
 
 
 def optimiser_step(world, dist, system="cartpole", total=256):
