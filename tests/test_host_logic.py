@@ -259,9 +259,13 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S",
                                        "--cuda-device-only", f"-DHJBX_MLP_ACT={act}"] + (["-fno-slp-vectorize"] if act == 3 else []) +
                                       ["-o", str(asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_mlp.hip")], stderr=subprocess.DEVNULL))
+    train_asm = tmp_path / "train.s"
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S", "--cuda-device-only",
+                                   "-fno-slp-vectorize", "-o", str(train_asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_train.hip")],
+                                  stderr=subprocess.DEVNULL))
     for pr in procs:
         assert pr.wait() == 0
-    for asm in outs:
+    for asm in outs + [train_asm]:
         assert audit_asm_loads.audit(str(asm)) == 0
     text = outs[0].read_text()
     assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
@@ -273,6 +277,10 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
         assert text.count(mfma) >= 30 * 288 and "ds_read_b64_tr_b16" in text
         scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
         assert len(scratch) == 30 and max(scratch) == 0, scratch
+    # the parameter-gradient chains (f32 and f16x2 instantiations): small stack objects are fine, REGISTER SPILLS are not
+    text = train_asm.read_text()
+    assert text.count("k_train_chains") > 36 and text.count("v_mfma_f32_32x32x16_f16") >= 18 * 384
+    assert "Folded Spill" not in text and "Folded Reload" not in text
 
 
 def test_graft_entry_build_check_passes():
