@@ -250,6 +250,13 @@ def lib() -> C.CDLL:
                 fn.restype = C.c_int
                 fn.argtypes = sig
         _lib = L
+        # HJBX_MLP_ARITHMETIC=f32|bf16x3|f16x2 in the environment selects the value-network arithmetic without code changes
+        want = os.environ.get("HJBX_MLP_ARITHMETIC", "").strip().lower()
+        if want:
+            modes = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+            if want not in modes:
+                raise RuntimeError(f"HJBX_MLP_ARITHMETIC must be one of {sorted(modes)}, got {want!r}")
+            L.hjbx_set_option(OPT_MLP_ARITHMETIC, modes[want])
         return L
 
 

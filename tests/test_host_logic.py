@@ -330,3 +330,15 @@ def test_value_network_arithmetic_option_roundtrip():
     with pytest.raises(Exception):
         pkg._abi.set_option(pkg._abi.OPT_MLP_ARITHMETIC, 3)
     assert pkg.value_network_arithmetic() == "f16x2"
+
+
+def test_value_network_arithmetic_from_the_environment():
+    """HJBX_MLP_ARITHMETIC in the environment sets the option when the library is loaded (fresh interpreter)."""
+    import subprocess
+    code = "import q_learning_with_hjb_amd as p; print(p.value_network_arithmetic())"
+    env = dict(os.environ, HJBX_MLP_ARITHMETIC="f32", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "f32", out.stderr[-400:]
+    env["HJBX_MLP_ARITHMETIC"] = "fp8"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "HJBX_MLP_ARITHMETIC" in out.stderr
