@@ -104,15 +104,21 @@ typedef enum hjbx_option {
                                               128 / 64-wide products of hjbx_value_loss_grad_f32 (mode 1 runs those on the f32 MFMA) (THE ONE KNOB
                                               THAT CHANGES RESULTS, within float32 rounding; inputs, outputs, accumulation, layer 1 and everything
                                               outside the network are float32 in every mode; tanh networks always run mode 0):
-                                              0 = float32 MFMA, bitwise an fmaf chain (the slowest: 1 / 16 of the 16-bit matrix rate);
-                                              1 = bf16x3: every float32 operand split EXACTLY into three bfloat16 pieces, the six largest piece
+                                              0 (DEFAULT) = float32 MFMA, bitwise an fmaf chain: the arithmetic of the reference's float32 network
+                                                  (controller/vhjb.py:17-60);
+                                              1 = OPT-IN bf16x3: every float32 operand split EXACTLY into three bfloat16 pieces, the six largest piece
                                                   products on the bf16 matrix cores (dropped products <= 2^-23 of each term);
-                                              2 (DEFAULT) = f16x2: every operand scaled by a power of two (per weight matrix / per environment
-                                                  and product) and rounded to two float16 pieces = 22 significant bits, the three largest
-                                                  piece products on the f16 matrix cores (perturbation <= 3 x 2^-22 = 7e-7 of each term,
-                                                  against the path's 1e-5 tolerance).
-                                              All three meet the same per-element parity bounds against the float64 oracle
-                                              (tests/test_gpu_f32_parity.py runs every test in every mode). */
+                                              2 = OPT-IN f16x2: every operand scaled by a power of two (ONE exponent per weight matrix; one per
+                                                  environment and product for the activations) and rounded to two float16 pieces, the three
+                                                  largest piece products on the f16 matrix cores.  An operand within 2^16 of its scaling maximum
+                                                  keeps 22 significant bits (perturbation <= 3 x 2^-22 = 7e-7 of its term); a smaller one loses
+                                                  low bits of its lo piece (float16 subnormals), i.e. the error bound is ABSOLUTE: 2^-39 of the
+                                                  matrix's largest |weight| (of the environment's largest activation) per operand, so one outlier
+                                                  weight 2^17 above the rest degrades every other entry of its matrix.
+                                              Modes 1 and 2 are faster and narrower than the reference's arithmetic: never the default.
+                                              tests/test_gpu_f32_parity.py runs every test in every mode against the same bounds, and
+                                              test_fused_value_grad_split_arithmetics_stay_within_their_stated_bound checks modes 1 / 2 against
+                                              mode 0 on the device. */
 } hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */

@@ -12,8 +12,9 @@ _ARITHMETICS = {"f32": 0, "bf16x3": 1, "f16x2": 2}
 
 def set_value_network_arithmetic(name: str) -> str:
     """How the fused kernels form the float32 products of the ReLU value network (process-wide; include/hjbx.h HJBX_OPT_MLP_ARITHMETIC,
-    DESIGN.md 4.5): "f16x2" (default: two float16 pieces per operand, scaled per environment), "bf16x3" (three exact bfloat16 pieces) or
-    "f32" (the f32 MFMA, bitwise an fmaf chain; 2.8x slower).  Returns the previous setting."""
+    DESIGN.md 4.5): "f32" (default: the f32 MFMA, bitwise an fmaf chain -- the reference's float32 network arithmetic), or the faster opt-in
+    emulations "bf16x3" (three exact bfloat16 pieces per operand, 1.6x) and "f16x2" (two float16 pieces per operand, scaled per environment,
+    2.8x; narrower than float32: 22 significant bits).  Returns the previous setting."""
     if name not in _ARITHMETICS:
         raise ValueError(f"arithmetic must be one of {sorted(_ARITHMETICS)}, got {name!r}")
     prev = _abi.set_option(_abi.OPT_MLP_ARITHMETIC, _ARITHMETICS[name])
@@ -26,4 +27,4 @@ def value_network_arithmetic() -> str:
 
 __all__ = ["_abi", "EULER", "RK4", "ZOH", "RESIDUAL_NORMALISED", "RESIDUAL_RAW", "build_library", "set_value_network_arithmetic",
            "value_network_arithmetic"]
-__version__ = "0.2.0"
+__version__ = "0.3.0"

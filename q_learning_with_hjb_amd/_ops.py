@@ -283,11 +283,23 @@ def value_loss_grad(sys, task, mlp_desc, x, cost, done, mode=_abi.RESIDUAL_NORMA
     need = lib().hjbx_value_loss_grad_workspace_bytes(B)
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _tws.get(key)
-    if ws is None or ws.numel() < need:
+    if ws is None or ws.numel() < need or ws.numel() > 4 * need + (64 << 20):     # grow on demand; give a much larger one back (5 KB per sample)
+        ws = None
+        _tws.pop(key, None)
         ws = torch.empty((need + 255) // 256 * 256, dtype=torch.uint8, device=x.device)
         _tws[key] = ws
     check(lib().hjbx_value_loss_grad_f32(sys.ptr, ref(task), ref(mlp_desc), int(mode), _p(x), _p(cost), _p(done), _p(flat), _p(ws), B, _stream()))
     return flat
+
+
+def release_workspaces(stream=None):
+    """Drop the cached workspaces (reduce tickets, rollout flags, parameter-gradient scratch) of one stream handle, or of every stream
+    (`stream=None`).  They are re-created -- zero-filled where the kernels need that -- on next use.  Call it when a stream goes away, or
+    after a launch was aborted (a device fault, a killed kernel): the ticket / flag words are only guaranteed to be zero after launches
+    that ran to completion."""
+    for cache in (_ws, _rws, _tws):
+        for key in [k for k in cache if stream is None or k[1] == stream]:
+            del cache[key]
 
 
 def mix_gradients(flat, n_params, regularization, eps):

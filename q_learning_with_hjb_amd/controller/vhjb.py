@@ -539,16 +539,23 @@ class VHJBController(Controller):
         the single-process update on the concatenated minibatch.  Returns (total, hjb, termination) losses."""
         return self._update_core(self._dev(xs), self._dev(dones), self._dev(costs), regularization)
 
+    def value_loss_gradient(self, xs, dones, costs) -> torch.Tensor:
+        """flat = [d sum(hjb_loss)/dW1 | dW2 | dW3 | d sum(termination_loss)/dW1 | dW2 | dW3 | sum hjb, sum termination, #interior, #done] of this rank's
+        samples from the fused MFMA kernels (hjbx_value_loss_grad_f32), summed over the ranks by the ONE all-reduce of the data-parallel step
+        (RCCL under the nccl backend).  The division by the GLOBAL counts and the mix follow in hjbx_mix_gradients_f32 (vhjb.py:241, 253, 284)."""
+        flat = _ops.value_loss_grad(self.dynamics.system, self._task, self.value_function_approximator.descriptor(), xs, costs, dones,
+                                    self.residual_mode)
+        if self._distributed():
+            torch.distributed.all_reduce(flat, group=self.process_group)
+        return flat
+
     def _update_core(self, xs, dones, costs, regularization):
         """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph."""
         model_params = list(self.value_function_approximator.parameters())
         if self.fused_param_grad:
             # one C-ABI call: [d sum(hjb)/dW | d sum(termination)/dW | sum hjb, sum termination, #interior, #done] -- exactly the buffer
             # the data-parallel step all-reduces once; then the division by the (global) counts and the mix (vhjb.py:241, 253, 284)
-            flat = _ops.value_loss_grad(self.dynamics.system, self._task, self.value_function_approximator.descriptor(), xs, costs, dones,
-                                        self.residual_mode)
-            if self._distributed():
-                torch.distributed.all_reduce(flat, group=self.process_group)
+            flat = self.value_loss_gradient(xs, dones, costs)
             P = sum(p.numel() for p in model_params)
             mixed, losses = _ops.mix_gradients(flat, P, regularization, self.epsilon)     # counts, mix and the three losses in one launch
             grads, off = [], 0
@@ -677,10 +684,14 @@ class GraphedStep:
         dev = self.inputs[0].device
         saved_p = [p.detach().clone() for p in params]
         saved_s = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()} for p in params if p in optimizer.state}
-        side = torch.cuda.Stream(device=dev)
+        # warm-up AND capture run on this one side stream: the library's workspaces (_ops: reduce tickets, rollout flags, the parameter-
+        # gradient scratch) are cached per (device, stream), so the buffers the warm-up allocated -- and zero-filled, outside any capture --
+        # are exactly the ones the captured launches use (capturing on torch's default capture stream allocated every workspace a second
+        # time, in the graph's pool, and recorded their zero-fill as memset nodes)
+        side = self._stream = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(3):                      # allocates Adam's state, rocBLAS workspaces and this library's reduce workspace
+            for _ in range(3):                      # allocates Adam's state, rocBLAS workspaces and this library's workspaces
                 core(*self.inputs)
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():
@@ -691,8 +702,17 @@ class GraphedStep:
                         v.copy_(saved_s[p][k]) if p in saved_s else v.zero_()
                 p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.out = core(*self.inputs)
+
+    def __del__(self):
+        # the workspaces cached for this step's private stream die with it (5 KB of scratch per sample for the parameter gradient)
+        st = getattr(self, "_stream", None)
+        if st is not None:
+            try:
+                _ops.release_workspaces(st.cuda_stream)
+            except Exception:
+                pass
 
     def matches(self, *inputs) -> bool:
         return [tuple(t.shape) for t in inputs] == self.shapes

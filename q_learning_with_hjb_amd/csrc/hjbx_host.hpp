@@ -1,6 +1,7 @@
 // hjbx_host.hpp -- host-side conversion of the ABI descriptors (doubles) into the by-value kernel argument PODs and
 // the handle -> concrete device system dispatch.  Shared by hjbx_kernels.hip and hjbx_mlp.hip; not part of the ABI.
 #pragma once
+#include <atomic>
 #include <cstring>
 
 #include "hjbx_internal.hpp"
@@ -87,6 +88,27 @@ template <typename T, typename F> inline bool with_system(const hjbx_system* s, 
     return false;
 }
 
+
+// Compute units of the CURRENT device (sizes the persistent grids and their workspaces); cached per device ordinal, not per process:
+// a process that moves to a second GPU must not size its launches with the first one's count.  0 = no device.
+static constexpr int kMaxDevices = 64;
+inline int hjbx_current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices ? dev : -1;
+}
+inline int hjbx_device_cus() {
+    static std::atomic<int> n_cu[kMaxDevices];
+    const int dev = hjbx_current_device();
+    if (dev < 0) return 0;
+    int n = n_cu[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        n_cu[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 
 // integrator argument check shared by every stepping entry point: HJBX_ZOH needs a LINEAR handle created with Ad, Bd
 inline int check_integrator(const hjbx_system* s, int integ, const char* who) {

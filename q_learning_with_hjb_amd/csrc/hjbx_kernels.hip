@@ -34,7 +34,7 @@ int hjbx_set_error(int code, const char* fmt, ...) {
 }
 
 // process-wide knobs (include/hjbx.h: hjbx_option)
-static std::atomic<int> g_options[4] = {{0}, {0}, {0}, {2}};   // (HJBX_OPT_MLP_ARITHMETIC defaults to 2 = f16x2)
+static std::atomic<int> g_options[4] = {{0}, {0}, {0}, {0}};   // (HJBX_OPT_MLP_ARITHMETIC defaults to 0 = float32 MFMA, the reference's arithmetic)
 int hjbx_option_value(int option) { return (option >= 0 && option < 4) ? g_options[option].load(std::memory_order_relaxed) : 0; }
 
 #define HJBX_REQUIRE(cond, ...)                                  \
@@ -288,11 +288,14 @@ template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, uns
         const unsigned shard = blockIdx.x % kShards;
         const unsigned in_shard = (gridDim.x - shard + kShards - 1) / kShards;          // workgroups with blockIdx % kShards == shard
         unsigned* sc = cnt + shard * kShardStrideWords;
-        if (__hip_atomic_fetch_add(sc, 1u, HJBX_RLX_AGENT) == in_shard - 1) {
+        // the tickets are agent-scope RELEASE operations (paired with the acquire fence of the last arriver below): the ordering of
+        // record before ticket then holds by the memory model, not only by the explicit drain above
+        if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
             __hip_atomic_store(sc, 0u, HJBX_RLX_AGENT);                                 // every workgroup of this shard has arrived
             unsigned* top = cnt + kShards * kShardStrideWords;
             const unsigned nshards = gridDim.x < (unsigned)kShards ? gridDim.x : (unsigned)kShards;
-            if (__hip_atomic_fetch_add(top, 1u, HJBX_RLX_AGENT) == nshards - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                          // (the other workgroups' records of this shard)
+            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
                 __hip_atomic_store(top, 0u, HJBX_RLX_AGENT);
                 last = 1;
             }

@@ -243,7 +243,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     const MlpP<N>& p = p_s;
     const TaskP<float, N, M>& tk = tk_s;
     const Limits<float, M>& lim = lim_s;
-    const int lane = tid & 63, wave = tid >> 6;
+    // wave index and this workgroup's flag are wave uniform IN FACT; through readfirstlane they are uniform TO THE COMPILER too, so the
+    // tile group a wave works on (`grp`) lives in SGPRs and `if (grp < 0) grp = next_group()` is a scalar branch.  With `grp` in VGPRs
+    // that branch was an EXEC-predicated region, and a register-allocator spill store placed inside it ran with EXEC = 0 for waves
+    // that already had a group: the reload after the join returned garbage (round 2: n = 10 / m = 2 kernels with 14 spilled VGPRs
+    // produced wrong trajectories).  A CPU test also keeps every instantiation at zero scratch.
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned my_flag_u = (unsigned)__builtin_amdgcn_readfirstlane((int)my_flag);
     const auto c = [&] {
         if constexpr (AR == 1) return mlp_ctx_x3<N>(L, lane);
         else if constexpr (AR == 2) return mlp_ctx_h2<N>(L, lane);
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
         if (victim < 0) {
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&q_next[simd], 1);
-            const int64_t g = my_flag == 0u ? group_of(blockIdx.x, simd + 4 * (int64_t)__builtin_amdgcn_readfirstlane(nxt)) : -1;
+            const int64_t g = my_flag_u == 0u ? group_of(blockIdx.x, simd + 4 * (int64_t)__builtin_amdgcn_readfirstlane(nxt)) : -1;
             if (g >= 0) return g;
             victim = 0;
             unsigned started = 0;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
     };
     int64_t grp;
     if (sched == 1) grp = (int64_t)blockIdx.x * WAVES + wave < ngroups ? (int64_t)blockIdx.x * WAVES + wave : -1;
-    else grp = my_flag == 0u ? group_of(blockIdx.x, wave) : -1;   // wave = simd + 4 * (wave >> 2): the first WAVES / 4 picks of each SIMD are static
+    else grp = my_flag_u == 0u ? group_of(blockIdx.x, wave) : -1;   // wave = simd + 4 * (wave >> 2): the first WAVES / 4 picks of each SIMD are static
     if (grp < 0) grp = next_group();
     while (grp >= 0) {
         const int64_t slot = grp * 32 + i;
@@ -387,14 +393,8 @@ template <typename S> static int launch_value_grad(S sys, const hjbx_mlp* mlp, c
     for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.istd[k] = (float)(1.0 / mlp->std[k]); p.xf[k] = (float)mlp->xf[k]; }
     p.eps_s = (float)mlp->eps_scalar;
     const int64_t ngroups = (B + 32 * TL - 1) / (32 * TL);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_grad_f32: no HIP device");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = hjbx_device_cus();
+    if (n_cu <= 0) return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_grad_f32: no HIP device");
     // one resident workgroup per CU (106 KB of LDS each); small batches are spread one tile group per CU
     // rather than packed eight to a workgroup, so up to n_cu matrix pipes work on them
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;
@@ -471,14 +471,8 @@ static int launch_vhjb_rollout(const hjbx_system* sysh, S sys, const hjbx_task* 
     const auto lim = make_limits<float, M>(sysh);
     RolloutOut<N, M> o{traj, u_log, cost, done, resid, done_step, x_out};
     const int64_t ngroups = (B + 31) / 32;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return hjbx_set_error(HJBX_ENODEVICE, "hjbx_vhjb_rollout_f32: no HIP device");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = hjbx_device_cus();
+    if (n_cu <= 0) return hjbx_set_error(HJBX_ENODEVICE, "hjbx_vhjb_rollout_f32: no HIP device");
     int64_t grid = ngroups < n_cu ? ngroups : n_cu;  // as in launch_value_grad
     const int sched = hjbx_option_value(HJBX_OPT_ROLLOUT_SCHEDULE);
     grid += hjbx_option_value(HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS);   // test hook: workgroups that cannot be resident before others finish

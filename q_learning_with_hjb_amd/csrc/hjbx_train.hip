@@ -569,16 +569,7 @@ extern "C" int hjbx_mix_gradients_f32(const float* flat, int64_t n_params, const
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-static int device_cus() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n_cu;
-}
+static int device_cus() { return hjbx_device_cus(); }   // per device ordinal (hjbx_host.hpp)
 
 struct TrainWs { size_t scratch, partial, sums, total; int64_t ntiles; int n_cu; };
 static TrainWs train_ws(int64_t B) {
@@ -629,12 +620,14 @@ static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, c
             if (h2) chains(std::integral_constant<int, 1>{}, std::true_type{});
             else chains(std::integral_constant<int, 1>{}, std::false_type{});
         }
-        static bool attr_set = false;   // 160 KiB of dynamic LDS need the opt-in once per kernel
+        static std::atomic<bool> attr_set[kMaxDevices];   // 160 KiB of dynamic LDS need the opt-in once per kernel AND DEVICE
         const size_t lds_bytes = 2 * (size_t)kImgFloats * sizeof(float);
-        if (!attr_set) {
+        const int dev = hjbx_current_device();
+        if (dev < 0) return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_loss_grad_f32: no HIP device");
+        if (!attr_set[dev].load(std::memory_order_relaxed)) {
             if (hipFuncSetAttribute((const void*)k_train_outer<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
                 return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: cannot reserve %zu bytes of LDS", lds_bytes);
-            attr_set = true;
+            attr_set[dev].store(true, std::memory_order_relaxed);
         }
         hipLaunchKernelGGL((k_train_outer<N>), dim3(gridB), dim3(512), lds_bytes, s, scratch, partial, w.ntiles);
         const int nthreads = kBlocks * 1024 + 4;

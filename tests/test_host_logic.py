@@ -267,20 +267,37 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
         assert pr.wait() == 0
     for asm in outs + [train_asm]:
         assert audit_asm_loads.audit(str(asm)) == 0
+        # the other direction (round 2's planar-quadrotor bug class): no inline-asm VALU statement reads an MFMA result still in flight
+        assert audit_asm_loads.audit_mfma_asm_reads(str(asm)) == 0
+    # ... and the audit does see such a read when there is one
+    probe = tmp_path / "probe.s"
+    probe.write_text("_Z5probev:\n\tv_mfma_f32_32x32x16_f16 v[64:79], v[0:3], v[4:7], v[64:79]\n\ts_nop 7\n\t;;#ASMSTART\n\tv_and_b32_e32 v30, v30, v64\n\t;;#ASMEND\n"
+                     "\tv_mfma_f32_32x32x16_f16 v[80:95], v[0:3], v[4:7], v[80:95]\n\ts_nop 15\n\t;;#ASMSTART\n\tv_and_b32_e32 v31, v31, v80\n\t;;#ASMEND\n\ts_endpgm\n")
+    assert audit_asm_loads.audit_mfma_asm_reads(str(probe)) == 1
     text = outs[0].read_text()
     assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
-    # the split-operand kernels run at 243-256 VGPRs: no instantiation may fall back on scratch (a spilled value is reloaded behind an
-    # `s_waitcnt vmcnt(0)` that drains the log stores, and round 2 saw rollout kernels with scratch leave tiles unprocessed)
+    # No MFMA inference kernel of ANY variant (f32 relu, f32 tanh, bf16x3, f16x2) may fall back on scratch: most sit at 250-256 VGPRs, a
+    # spilled value is reloaded behind an `s_waitcnt vmcnt(0)` that drains the log stores, and round 2 saw rollout kernels whose spill
+    # store sat in an EXEC = 0 region return wrong trajectories (the cause -- a divergent `grp` -- is removed as well).
     import re
-    for asm, mfma in ((outs[2], "v_mfma_f32_32x32x16_bf16"), (outs[3], "v_mfma_f32_32x32x16_f16")):
+    meta = re.compile(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)")
+    for asm, mfma, per in ((outs[0], "v_mfma_f32_32x32x2_f32", 700), (outs[1], "v_mfma_f32_32x32x2_f32", 700), (outs[2], "v_mfma_f32_32x32x16_bf16", 288),
+                           (outs[3], "v_mfma_f32_32x32x16_f16", 288)):
         text = asm.read_text()
-        assert text.count(mfma) >= 30 * 288 and "ds_read_b64_tr_b16" in text
-        scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
-        assert len(scratch) == 30 and max(scratch) == 0, scratch
+        assert text.count(mfma) >= 30 * per
+        kernels = meta.findall(text)
+        assert len(kernels) == 30 and sum("k_vhjb_rollout_mfma" in k[0] for k in kernels) == 24 and sum("k_value_grad_mfma" in k[0] for k in kernels) == 6
+        for name, private, _sgpr_spill, vgpr_spill in kernels:
+            assert int(private) == 0 and int(vgpr_spill) == 0, f"{name}: {private} bytes of scratch, {vgpr_spill} spilled VGPRs"
+        if asm in (outs[2], outs[3]):
+            assert "ds_read_b64_tr_b16" in text
+        # `grp` is wave uniform to the compiler: taking the next tile group is a scalar branch, not an EXEC-masked region
     # the parameter-gradient chains (f32 and f16x2 instantiations): small stack objects are fine, REGISTER SPILLS are not
     text = train_asm.read_text()
     assert text.count("k_train_chains") > 36 and text.count("v_mfma_f32_32x32x16_f16") >= 18 * 384
     assert "Folded Spill" not in text and "Folded Reload" not in text
+    for name, _private, _sgpr_spill, vgpr_spill in meta.findall(text):
+        assert int(vgpr_spill) == 0, f"{name}: {vgpr_spill} spilled VGPRs"
 
 
 def test_graft_entry_build_check_passes():
@@ -319,26 +336,35 @@ def test_oracle_passes_address_and_ub_sanitizers():
 
 
 def test_value_network_arithmetic_option_roundtrip():
-    """hjbx_set_option(HJBX_OPT_MLP_ARITHMETIC): default f16x2, query with a negative value, rejects unknown modes (host logic only)."""
+    """hjbx_set_option(HJBX_OPT_MLP_ARITHMETIC): the default is f32 (the reference's arithmetic; the 16-bit split modes are opt-in), query
+    with a negative value, rejects unknown modes (host logic only)."""
     import q_learning_with_hjb_amd as pkg
-    assert pkg.value_network_arithmetic() == "f16x2"
-    assert pkg.set_value_network_arithmetic("f32") == "f16x2" and pkg.value_network_arithmetic() == "f32"
-    assert pkg.set_value_network_arithmetic("bf16x3") == "f32"
-    assert pkg.set_value_network_arithmetic("f16x2") == "bf16x3"
-    with pytest.raises(ValueError):
-        pkg.set_value_network_arithmetic("fp8")
-    with pytest.raises(Exception):
-        pkg._abi.set_option(pkg._abi.OPT_MLP_ARITHMETIC, 3)
-    assert pkg.value_network_arithmetic() == "f16x2"
+    if not os.environ.get("HJBX_MLP_ARITHMETIC"):
+        assert pkg.value_network_arithmetic() == "f32"
+    prev = pkg.set_value_network_arithmetic("f32")
+    try:
+        assert pkg.set_value_network_arithmetic("f16x2") == "f32" and pkg.value_network_arithmetic() == "f16x2"
+        assert pkg.set_value_network_arithmetic("bf16x3") == "f16x2"
+        assert pkg.set_value_network_arithmetic("f32") == "bf16x3"
+        with pytest.raises(ValueError):
+            pkg.set_value_network_arithmetic("fp8")
+        with pytest.raises(Exception):
+            pkg._abi.set_option(pkg._abi.OPT_MLP_ARITHMETIC, 3)
+        assert pkg.value_network_arithmetic() == "f32"
+    finally:
+        pkg.set_value_network_arithmetic(prev)
 
 
 def test_value_network_arithmetic_from_the_environment():
     """HJBX_MLP_ARITHMETIC in the environment sets the option when the library is loaded (fresh interpreter)."""
     import subprocess
     code = "import q_learning_with_hjb_amd as p; print(p.value_network_arithmetic())"
-    env = dict(os.environ, HJBX_MLP_ARITHMETIC="f32", PYTHONPATH=ROOT)
+    env = dict(os.environ, HJBX_MLP_ARITHMETIC="f16x2", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "f32", out.stderr[-400:]
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "f16x2", out.stderr[-400:]
+    env.pop("HJBX_MLP_ARITHMETIC")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "f32", out.stderr[-400:]       # the library default
     env["HJBX_MLP_ARITHMETIC"] = "fp8"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "HJBX_MLP_ARITHMETIC" in out.stderr
