@@ -375,6 +375,24 @@ def optimiser_step(world, dist, system="cartpole", total=256):
                 mode=("hipGraph replay" if ctl.graph_updates else "eager launches" + (" + one flat all-reduce" if world > 1 else "")))
 
 
+def strong_scaling_line(world, rank, dist, barrier, system="quad2d", total=1 << 18, K=40, W=10, reps=3):
+    """BASELINE configs[3] as a STRONG-scaling measurement: `total` planar quadrotors in all, rank r rolls out the contiguous shard
+    [r total / G, (r + 1) total / G) (2^18 -> 8 x 2^15 on a full node); no data-path collective; time = max over ranks per repetition."""
+    lo, hi = rank * total // world, (rank + 1) * total // world
+    wl = make_workload(system, "euler", "relu", hi - lo, 1000 + rank)
+    walls, _, live = time_fused(wl, K, W, reps, 0, barrier, prewarm=0.0)
+    wt = torch.tensor(walls, device="cuda", dtype=torch.float64)
+    lt = torch.tensor([live], device="cuda", dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lt)
+    el = float(np.median(wt.cpu().numpy()))
+    del wl
+    torch.cuda.empty_cache()
+    return dict(name=f"strong scaling: fused vhjb rollout, {system}, 2^{int(np.log2(total))} environments IN TOTAL over {world} rank(s) (BASELINE configs[3])",
+                value=int(lt.item()) / el, unit="env-steps/s", ms_per_step=el / K * 1e3, ranks=world, shard=hi - lo, scaling="strong", arithmetic=ARITHMETIC)
+
+
 def parity_evidence(arith, system):
     """What the GPU parity tests measured for this arithmetic (tests/test_gpu_f32_parity.py writes the report; the committed copy is
     profiles/r02_f32_parity_report.json): per-element errors of one teacher-forced step at full batch against the f64 oracle, as a
@@ -418,11 +436,13 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         t = torch.tensor([rank + 1], dtype=torch.int64)
         dist.all_reduce(t)
+        one = torch.ones(1)
+        dist.all_reduce(one)                                     # the same `ranks_seen` probe the measured run does on the device
         total = args.batch or HEADLINE_BATCH[args.system]
         shard = [(r * total // world, (r + 1) * total // world) for r in range(world)] if args.scaling == "strong" else None
         if rank == 0:
             sys.stdout.flush()
-            os.write(stdout_fd, (json.dumps(dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()), scaling=args.scaling, steps=args.steps, warmup=args.warmup,
+            os.write(stdout_fd, (json.dumps(dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()), ranks_seen=int(one.item()), scaling=args.scaling, steps=args.steps, warmup=args.warmup,
                                                  global_batch=total if args.scaling == "strong" else total * world, shards=shard)) + "\n").encode())
         dist.barrier()
         dist.destroy_process_group()
@@ -443,6 +463,16 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
+
+    # proof that the collective backend really spans N ranks: an all-reduce of ones on the DEVICE (RCCL under the nccl backend) must
+    # return N on every rank; it goes into the JSON line as `ranks_seen`
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device="cuda")
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one.item())))
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: the {args.backend} all-reduce saw {ranks_seen} ranks, expected {world}")
 
     import q_learning_with_hjb_amd as pkg
     if rank == 0:
@@ -481,7 +511,12 @@ def main():
 
     walls_t = torch.tensor(walls, device="cuda", dtype=torch.float64)
     live_t = torch.tensor([live], device="cuda", dtype=torch.int64)
+    per_rank_ms = [float(np.median(walls)) / K * 1e3]
     if dist is not None:
+        mine = torch.tensor([per_rank_ms[0]], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)                          # every rank's own median (before the max over ranks below)
+        per_rank_ms = [float(t.item()) for t in allr]
         dist.all_reduce(walls_t, op=dist.ReduceOp.MAX)      # per repetition: the slowest rank
         dist.all_reduce(live_t)
     walls = walls_t.cpu().numpy()
@@ -495,6 +530,7 @@ def main():
                dtype={"f32": "f32", "bf16x3": "f32 (value-network products as exact 3-way bf16 splits on the bf16 MFMA, f32 accumulation)",
                       "f16x2": "f32 (value-network products as scaled 2-way f16 splits, 22 bits, on the f16 MFMA, f32 accumulation)"}[args.arithmetic],
                data="synthetic", reps=reps, ms_per_step_min=float(walls.min()) / K * 1e3, ms_per_step_max=float(walls.max()) / K * 1e3,
+               ranks_seen=ranks_seen, per_rank_ms_per_step=per_rank_ms,
                config=dict(workload=wl["label"], batch_per_gpu=B, global_batch=global_batch,
                            state_dim=n, control_dim=m, integrator=args.integrator, mlp=f"{n}-128-128-64 {args.activation}, no bias",
                            value_grad=("persistent fused rollout kernel (MFMA value net + step)" if fused else
@@ -534,10 +570,11 @@ def main():
             torch.cuda.empty_cache()
             sec.append(param_gradient_kernels("nearhover", 1 << 20))
             torch.cuda.empty_cache()
+        sec_strong = strong_scaling_line(world, rank, dist, barrier)   # configs[3]: 2^18 planar quadrotors IN TOTAL, sharded over the ranks
         sec_opt = optimiser_step(world, dist)                  # every rank takes part (all-reduce inside for G > 1)
         sec_big = optimiser_step(world, dist, "nearhover", (1 << 20) * world)     # configs[4]: the sharded full-batch learning step
         if rank == 0:
-            sec += [sec_opt, sec_big]
+            sec += [sec_strong, sec_opt, sec_big]
             out["secondary"] = sec
 
     if rank == 0:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 105 /* major*100 + minor */
+#define HJBX_VERSION 106 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -50,8 +50,19 @@ typedef enum hjbx_system_kind {
     HJBX_SYS_CARTPOLE = 1,  /* dynamics/cartpole.py:10-64   params = mc, mp, l, g                    */
     HJBX_SYS_ACROBOT = 2,   /* dynamics/acrobot.py:19-81    params = m1, m2, l1, l2, I1, I2, g       */
     HJBX_SYS_QUAD2D = 3,    /* dynamics/quadrotors.py:9-70  params = m, r, I, g                      */
-    HJBX_SYS_NEARHOVER = 4  /* dynamics/quadrotors.py:102-170 params = g, m, kT, n0                  */
+    HJBX_SYS_NEARHOVER = 4, /* dynamics/quadrotors.py:102-170 params = g, m, kT, n0                  */
+    HJBX_SYS_USER = 5       /* a user-defined Dynamics subclass: created by hjbx_system_create_from_source only */
 } hjbx_system_kind;
+
+/* What a user-defined system supplies (hjbx_system_create_from_source). */
+typedef enum hjbx_user_kind {
+    HJBX_USER_AFFINE = 0,      /* the subclass overrides get_control_affine_matrix (like dynamics/linear.py:20-22, quadrotors.py:17-46):
+                                  the source defines wrap(x) and affine(x, f1, f2) */
+    HJBX_USER_MANIPULATOR = 1  /* the subclass defines get_M / get_C / get_G / get_B and inherits the generic manipulator form
+                                  f1 = [dq; -inv(M)(C dq + G)], f2 = [0; inv(M) B] (dynamics/dynamics_basic.py:64-94): the source
+                                  defines wrap(x), get_M, get_C, get_G, get_B; n even, q = x[:n/2] */
+} hjbx_user_kind;
+#define HJBX_USER_MAX_PARAMS 16
 
 typedef enum hjbx_integrator {
     HJBX_EULER = 0, /* x' = wrap(x + dt*xdot): the reference's integrator, dynamics_basic.py:120 (parity mode) */
@@ -188,6 +199,19 @@ int hjbx_set_option(int option, int value);
 int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, const double* umax,
                        const double* params, int n_params, hjbx_system** out);
 void hjbx_system_destroy(hjbx_system* sys);
+/* The OPEN half of the reference's plugin surface: "any subclass of Dynamics" (dynamics/dynamics_basic.py:7-122).  `device_source` is the text
+ * of the subclass's per-state methods as device code (member functions of a struct template on the scalar type T with the parameters in
+ * p[0..n_params-1]; the exact contract is at the top of csrc/hjbx_user_kernels.hpp).  It is compiled at run time (hiprtc, gfx950, the
+ * library's own build flags) INTO THE LIBRARY'S OWN STREAMING KERNELS, float32 and float64: the returned handle works with every
+ * hjbx_*_f32 / _f64 entry point of the HJBX_DECLARE block below (wrap, affine, dynamics_step, simulate with HJBX_EULER / HJBX_RK4,
+ * initial_state, costs, control_from_grad, hjb_residual, vhjb_step, controller and rollout_feedback with HJBX_CTRL_LINEAR_FEEDBACK).
+ * The matrix-core entry points (hjbx_value_grad_f32, hjbx_vhjb_rollout_f32, hjbx_value_loss_grad_f32) exist for the built-in systems
+ * only and return HJBX_EUNSUPPORTED for such a handle.  Compilation needs no GPU.  HJBX_EINVAL when the source does not compile
+ * (hjbx_last_compile_log returns the compiler's messages for the calling thread's last call), HJBX_EUNSUPPORTED when libhiprtc.so
+ * is not available. */
+int hjbx_system_create_from_source(int user_kind, const char* device_source, int n, int m, double dt, const double* umin,
+                                   const double* umax, const double* params, int n_params, hjbx_system** out);
+size_t hjbx_last_compile_log(char* buf, size_t buflen);
 /* Dynamics.get_dimension, dynamics_basic.py:31-36 */
 int hjbx_dims(const hjbx_system* sys, int* n, int* m);
 /* Bytes of device scratch the reducing entry points need (hjb_residual, termination_residual).  The workspace holds the

@@ -16,7 +16,9 @@ HJBX_MAX_N = 10
 HJBX_MAX_M = 3
 
 # enums of include/hjbx.h
-SYS_LINEAR, SYS_CARTPOLE, SYS_ACROBOT, SYS_QUAD2D, SYS_NEARHOVER = range(5)
+SYS_LINEAR, SYS_CARTPOLE, SYS_ACROBOT, SYS_QUAD2D, SYS_NEARHOVER, SYS_USER = range(6)
+USER_AFFINE, USER_MANIPULATOR = 0, 1
+USER_MAX_PARAMS = 16
 EULER, RK4, ZOH = 0, 1, 2
 RESIDUAL_NORMALISED, RESIDUAL_RAW = 0, 1
 CTRL_LINEAR_FEEDBACK, CTRL_CARTPOLE_ENERGY, CTRL_ACROBOT_ENERGY, CTRL_DI_TIME_OPTIMAL = 0, 1, 2, 3
@@ -35,9 +37,11 @@ _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=2",), "hjbx_mlp_x3.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=3", "-fno-slp-vectorize"), "hjbx_mlp_h2.o"),
-          ("hjbx_train.hip", ("-fno-slp-vectorize",), "hjbx_train.o"))
+          ("hjbx_train.hip", ("-fno-slp-vectorize",), "hjbx_train.o"),
+          ("hjbx_user.hip", (f'-DHJBX_CSRC_DIR="{_CSRC}"',), "hjbx_user.o"))       # embeds three headers as text for hiprtc (.incbin)
 _SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
-_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", "hjbx_mlp_x3.hpp", "hjbx_mlp_h2.hpp", os.path.join("..", "..", "include", "hjbx.h"))
+_HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", "hjbx_mlp_x3.hpp", "hjbx_mlp_h2.hpp", "hjbx_stream_kernels.hpp",
+            "hjbx_user_kernels.hpp", os.path.join("..", "..", "include", "hjbx.h"))
 
 
 class HjbxTask(C.Structure):
@@ -196,7 +200,8 @@ def _typed_signatures():
 
 
 EXPORTED_SYMBOLS = (
-    ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_set_option", "hjbx_system_create", "hjbx_system_destroy", "hjbx_dims",
+    ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_set_option", "hjbx_system_create", "hjbx_system_create_from_source",
+     "hjbx_last_compile_log", "hjbx_system_destroy", "hjbx_dims",
      "hjbx_reduce_workspace_bytes", "hjbx_rollout_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32",
      "hjbx_value_loss_grad_workspace_bytes", "hjbx_value_loss_grad_f32", "hjbx_mix_gradients_f32"]
     + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
@@ -230,6 +235,10 @@ def lib() -> C.CDLL:
         L.hjbx_set_option.argtypes = [C.c_int, C.c_int]
         L.hjbx_system_create.restype = C.c_int
         L.hjbx_system_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]
+        L.hjbx_system_create_from_source.restype = C.c_int
+        L.hjbx_system_create_from_source.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_double, _VP, _VP, _VP, C.c_int, C.POINTER(_VP)]
+        L.hjbx_last_compile_log.restype = C.c_size_t
+        L.hjbx_last_compile_log.argtypes = [C.c_char_p, C.c_size_t]
         L.hjbx_system_destroy.restype = None
         L.hjbx_system_destroy.argtypes = [_VP]
         L.hjbx_dims.restype = C.c_int
@@ -278,6 +287,14 @@ def last_error() -> str:
     return buf.value.decode("utf-8", "replace")
 
 
+def compile_log() -> str:
+    """The hiprtc log of the calling thread's last hjbx_system_create_from_source."""
+    n = lib().hjbx_last_compile_log(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib().hjbx_last_compile_log(buf, n + 1)
+    return buf.value.decode("utf-8", "replace")
+
+
 def check(rc: int):
     """Turn an hjbx_status into the exception the Python surface promises (Errors)."""
     if rc == OK:
@@ -302,6 +319,27 @@ class SystemHandle:
         check(lib().hjbx_system_create(self.kind, self.n, self.m, self.dt, self.umin.ctypes.data, self.umax.ctypes.data,
                                        self.params.ctypes.data, int(self.params.size), C.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_source(cls, user_kind, device_source: str, n, m, dt, umin, umax, params):
+        """hjbx_system_create_from_source: a user-defined system compiled at run time into the library's streaming kernels
+        (include/hjbx.h; the snippet contract is at the top of csrc/hjbx_user_kernels.hpp).  ValueError with the compiler's log when the
+        source does not compile."""
+        self = cls.__new__(cls)
+        self.kind, self.n, self.m, self.dt = SYS_USER, int(n), int(m), float(dt)
+        self.umin = np.ascontiguousarray(umin, np.float64).reshape(m)
+        self.umax = np.ascontiguousarray(umax, np.float64).reshape(m)
+        self.params = np.ascontiguousarray(params, np.float64).ravel()
+        self.user_kind, self.device_source = int(user_kind), str(device_source)
+        h = _VP()
+        rc = lib().hjbx_system_create_from_source(self.user_kind, self.device_source.encode(), self.n, self.m, self.dt, self.umin.ctypes.data,
+                                                  self.umax.ctypes.data, self.params.ctypes.data if self.params.size else None,
+                                                  int(self.params.size), C.byref(h))
+        if rc == EINVAL and compile_log():
+            raise ValueError(f"hjbx: {last_error()}\n--- compiler log ---\n{compile_log()}")
+        check(rc)
+        self._h = h
+        return self
 
     @property
     def ptr(self):

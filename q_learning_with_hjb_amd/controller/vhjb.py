@@ -292,7 +292,10 @@ class VHJBController(Controller):
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen, activation=activation)
         # activation: "relu" = controller/vhjb.py; "tanh" / "sin" = the notebooks' networks ("sin": PyTorch path only)
-        fusable = activation in ValueFunctionApproximator.FUSED_ACTIVATIONS
+        # the matrix-core kernels carry the five built-in systems; a user-defined system (Dynamics.device_source) runs the value network
+        # through PyTorch and its own run-time compiled step / residual kernels
+        builtin = dynamics.system.kind != _abi.SYS_USER
+        fusable = activation in ValueFunctionApproximator.FUSED_ACTIVATIONS and builtin
         self.fused_value_grad = (dtype == torch.float32 and fusable) if fused_value_grad is None else bool(fused_value_grad)
         if self.fused_value_grad and not fusable:
             raise NotImplementedError(f"no fused value-gradient kernel for the {activation} activation")
@@ -300,7 +303,7 @@ class VHJBController(Controller):
         # residuals and the second-order reverse sweep in closed form) for the float32 ReLU network of controller/vhjb.py; anything else
         # (float64, tanh / sin, HJBX_FUSED_PARAM_GRAD=0) goes through PyTorch autograd
         can_fuse_pg = (dtype == torch.float32 and activation == "relu" and tuple(config.features) == (128, 128, 64) and self.device.type == "cuda"
-                       and not config.using_batch_norm)
+                       and not config.using_batch_norm and builtin)
         if fused_param_grad is None:
             fused_param_grad = can_fuse_pg and os.environ.get("HJBX_FUSED_PARAM_GRAD", "1") != "0"
         if fused_param_grad and not can_fuse_pg:

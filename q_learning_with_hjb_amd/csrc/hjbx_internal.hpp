@@ -9,7 +9,12 @@ struct hjbx_system {
     double umin[HJBX_MAX_M], umax[HJBX_MAX_M];
     double p[2 * (HJBX_MAX_N * HJBX_MAX_N + HJBX_MAX_N * HJBX_MAX_M)];  // packing documented at hjbx_system_kind
     int n_params;
+    void* user;   // HJBX_SYS_USER: the run-time compiled program (hjbx_user.hip); NULL otherwise
 };
+
+// HJBX_SYS_USER (hjbx_user.hip): launch an extern "C" kernel of the handle's code object (args[0] points at the system blob), and free it
+int hjbx_user_launch(const hjbx_system* s, const char* kernel, unsigned grid, void** args, void* stream);
+void hjbx_user_release(void* user_program);
 
 // records the calling thread's error message and returns `code`
 int hjbx_set_error(int code, const char* fmt, ...);

@@ -17,8 +17,10 @@
 #include "hjbx_internal.hpp"
 #include "hjbx_systems.hpp"
 #include "hjbx_host.hpp"
+#include "hjbx_stream_kernels.hpp"
 
 using namespace hjbx;
+static_assert(kRolloutTerminate == HJBX_ROLLOUT_TERMINATE && kRolloutStopAtTarget == HJBX_ROLLOUT_STOP_AT_TARGET, "rollout flags");
 
 // ----------------------------------------------------------------------------------------------
 // error plumbing
@@ -48,41 +50,8 @@ static int check_launch(const char* what) {
     return HJBX_OK;
 }
 
-// ----------------------------------------------------------------------------------------------
-// row-vector global memory access: a (B, N) row-major row is moved with the widest naturally
-// aligned vector the row size allows (16 B for n=4 f32: one global_load_dwordx4 per lane).
-// ----------------------------------------------------------------------------------------------
-template <int BYTES> struct VecOf;
-template <> struct VecOf<16> { using type = uint4; };
-template <> struct VecOf<8> { using type = uint2; };
-template <> struct VecOf<4> { using type = uint32_t; };
-
-template <typename T, int N> struct RowIO {
-    static constexpr int BYTES = N * (int)sizeof(T);
-    static constexpr int W = (BYTES % 16 == 0) ? 16 : (BYTES % 8 == 0) ? 8 : 4;
-    static constexpr int CNT = BYTES / W;
-    using V = typename VecOf<W>::type;
-    static HJBX_DEV void load(const T* base, int64_t row, T* out) {
-        const V* p = reinterpret_cast<const V*>(base + row * N);
-        union { V v[CNT]; T t[N]; } u;
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) u.v[k] = p[k];
-#pragma unroll
-        for (int i = 0; i < N; ++i) out[i] = u.t[i];
-    }
-    static HJBX_DEV void store(T* base, int64_t row, const T* in) {
-        V* p = reinterpret_cast<V*>(base + row * N);
-        union { V v[CNT]; T t[N]; } u;
-#pragma unroll
-        for (int i = 0; i < N; ++i) u.t[i] = in[i];
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) p[k] = u.v[k];
-    }
-};
-
-static constexpr int kBlock = 256;        // 4 waves per workgroup
-static constexpr int kReduceBlocks = 1024;  // grid cap of the reducing kernels (4 per CU); 4096 measured no better
-
+// The kernels themselves are the device function templates of hjbx_stream_kernels.hpp (shared with the run-time compiled user systems of
+// hjbx_user.hip); here: their __global__ wrappers for the built-in systems, and the host side of the C ABI.
 static inline dim3 grid_for(int64_t B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
 static inline dim3 grid_rows(int64_t B, int R) { return dim3((unsigned)((B + (int64_t)kBlock * R - 1) / ((int64_t)kBlock * R))); }
 // rows per thread of the streaming kernels: enough loads in flight to cover the HBM latency once the batch fills the chip; small
@@ -98,316 +67,82 @@ template <typename T> static inline int rows_per_thread(int64_t B, int n, bool r
     return reducing && B >= (1 << 18) ? 2 : 1;
 }
 
-// ----------------------------------------------------------------------------------------------
-// pointwise kernels
-// ----------------------------------------------------------------------------------------------
+
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_affine(S sys, const T* __restrict__ x, T* __restrict__ f1,
                                                    T* __restrict__ f2, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], a[S::N], b[S::N * S::M];
-    RowIO<T, S::N>::load(x, i, xs);
-    sys.affine(xs, a, b);
-    RowIO<T, S::N>::store(f1, i, a);
-    RowIO<T, S::N * S::M>::store(f2, i, b);
+    k_affine_body<S, T>(sys, x, f1, f2, B);
 }
 
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_wrap(S sys, const T* x, T* out, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N];
-    RowIO<T, S::N>::load(x, i, xs);
-    sys.wrap(xs);
-    RowIO<T, S::N>::store(out, i, xs);
+    k_wrap_body<S, T>(sys, x, out, B);
 }
 
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_xdot(S sys, const T* __restrict__ x, const T* __restrict__ u,
                                                  T* __restrict__ xd, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], us[S::M], d[S::N];
-    RowIO<T, S::N>::load(x, i, xs);
-    RowIO<T, S::M>::load(u, i, us);
-    // f1 + f2 @ u, evaluated like the reference (dynamics_basic.py:101-103)
-    T f1[S::N], f2[S::N * S::M];
-    sys.affine(xs, f1, f2);
-#pragma unroll
-    for (int r = 0; r < S::N; ++r) {
-        T acc = T(0);
-#pragma unroll
-        for (int j = 0; j < S::M; ++j) acc += f2[r * S::M + j] * us[j];
-        d[r] = f1[r] + acc;
-    }
-    RowIO<T, S::N>::store(xd, i, d);
+    k_xdot_body<S, T>(sys, x, u, xd, B);
 }
 
-// R rows per thread, all loads issued before the first use: a 36 MB kernel at 6 TB/s lasts 6 us, and with one row per thread the
-// 16 workgroups a CU receives run as two resident rounds of (HBM latency + compute + store) -- latency bound, 4.1 TB/s measured
-// with buffers that miss the Infinity Cache (profiles/r02_kernel_bench.json).  Row r of a thread is block_base + r kBlock + tid,
-// so every load instruction of a wave stays one coalesced segment.
 template <int INTEG, int R, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_simulate(S sys, Limits<T, S::M> lim, const T* x, const T* __restrict__ u,
                                                      T* xn, int64_t B) {
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
-    T xs[R][S::N], us[R][S::M];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t i = base + r * kBlock;
-        if (i < B) {
-            RowIO<T, S::N>::load(x, i, xs[r]);
-            RowIO<T, S::M>::load(u, i, us[r]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t i = base + r * kBlock;
-        if (i < B) {
-            T uc[S::M], o[S::N];
-            clip_u<T, S::M>(lim, us[r], uc);
-            integrate<INTEG>(sys, lim.dt, xs[r], uc, o);
-            RowIO<T, S::N>::store(xn, i, o);
-        }
-    }
+    k_simulate_body<INTEG, R, S, T>(sys, lim, x, u, xn, B);
 }
-
-template <typename S, typename T> struct X0P { T mean[S::N], std[S::N]; };
 
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_initial_state(S sys, X0P<S, T> p, const T* __restrict__ u01,
                                                           T* __restrict__ x0, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T r[S::N], o[S::N];
-    RowIO<T, S::N>::load(u01, i, r);
-#pragma unroll
-    for (int k = 0; k < S::N; ++k) {
-        const T lo = -p.std[k], hi = p.std[k];  // np.random.uniform(low, high): low + (high-low)*u
-        o[k] = (lo + (hi - lo) * r[k]) + p.mean[k];
-    }
-    sys.wrap(o);
-    RowIO<T, S::N>::store(x0, i, o);
+    k_initial_state_body<S, T>(sys, p, u01, x0, B);
 }
 
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_running_cost(S sys, TaskP<T, S::N, S::M> tk, const T* __restrict__ x,
                                                          const T* __restrict__ u, T* __restrict__ cost, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], us[S::M], e[S::N];
-    RowIO<T, S::N>::load(x, i, xs);
-    RowIO<T, S::M>::load(u, i, us);
-    error_coords(sys, tk.xf, xs, e);
-    cost[i] = running_cost_e<S, T>(tk, e, us);
+    k_running_cost_body<S, T>(sys, tk, x, u, cost, B);
 }
 
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_termination_cost(S sys, TaskP<T, S::N, S::M> tk, const T* __restrict__ x,
                                                              T* __restrict__ cost, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], e[S::N];
-    RowIO<T, S::N>::load(x, i, xs);
-    error_coords(sys, tk.xf, xs, e);
-    cost[i] = quad_form<S::N>(tk.P, e);
+    k_termination_cost_body<S, T>(sys, tk, x, cost, B);
 }
 
 template <typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_control_from_grad(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim,
                                                               const T* __restrict__ x, const T* __restrict__ g,
                                                               T* __restrict__ u, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], gs[S::N], f1[S::N], f2[S::N * S::M], ur[S::M], uo[S::M];
-    RowIO<T, S::N>::load(x, i, xs);
-    RowIO<T, S::N>::load(g, i, gs);
-    sys.affine(xs, f1, f2);
-    control_from_grad<S, T>(tk, lim, f2, gs, ur, uo);
-    RowIO<T, S::M>::store(u, i, uo);
+    k_control_from_grad_body<S, T>(sys, tk, lim, x, g, u, B);
 }
 
 template <int CK, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_controller(S sys, CtrlP<T, S::N, S::M> c, Limits<T, S::M> lim,
                                                        const T* __restrict__ x, T* __restrict__ u, int64_t B) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T xs[S::N], uo[S::M];
-    RowIO<T, S::N>::load(x, i, xs);
-    controller_eval<CK>(sys, c, lim, xs, uo);
-    RowIO<T, S::M>::store(u, i, uo);
+    k_controller_body<CK, S, T>(sys, c, lim, x, u, B);
 }
 
-// ----------------------------------------------------------------------------------------------
-// deterministic 3-way sum inside ONE launch: lane partials (double) -> wave64 shuffle tree -> LDS across the 4 waves
-// -> one (3 x double) record per workgroup in the caller's workspace -> the workgroup that arrives LAST sums the
-// records in index order and writes `sums`.  No float atomics and a fixed summation order: results are bitwise
-// reproducible run to run.  (Round 1 did the last stage in a second single-wave launch: 5.7 us + a kernel boundary.)
-//
-// Cross-workgroup hand-off (guide 6 G16, R1 form): the record is stored write-through (8-byte agent-scope atomic stores =
-// global_store sc1), the storing wave drains them (s_waitcnt vmcnt(0)), then ONE lane takes a ticket with a returning
-// agent-scope atomic add.  Tickets are sharded over kShards counters (each on a 128-byte line of its own; the last arriver
-// of a shard takes a ticket of the top counter): 1024 workgroups finishing together would otherwise serialise on one word
-// (~11 ns per atomic).  The last arriver issues one agent-scope acquire and reads the records with agent-scope loads.
-// The counters are left at zero by the workgroups that saw the last tickets: the workspace must be zero-filled once after
-// allocation and is zero again after every call.
-// ----------------------------------------------------------------------------------------------
-static constexpr int kShards = 32;
-static constexpr int kShardStrideWords = 32;                                           // 128 bytes per counter
-static constexpr size_t kCounterBytes = (size_t)(kShards + 1) * kShardStrideWords * 4;  // shard counters + the top counter
-#define HJBX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-
-HJBX_DEV double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, unsigned char* ws, T* __restrict__ sums) {
-    __shared__ double lds[3][kBlock / 64];
-    a = wave_sum(a);
-    b = wave_sum(b);
-    c = wave_sum(c);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { lds[0][wave] = a; lds[1][wave] = b; lds[2][wave] = c; }
-    __syncthreads();
-    if (wave != 0) return;
-    unsigned* cnt = reinterpret_cast<unsigned*>(ws);
-    double* rec = reinterpret_cast<double*>(ws + kCounterBytes);
-    unsigned last = 0;
-    if (lane == 0) {
-        double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) { s0 += lds[0][w]; s1 += lds[1][w]; s2 += lds[2][w]; }
-        double* r = rec + 3 * (size_t)blockIdx.x;
-        __hip_atomic_store(r + 0, s0, HJBX_RLX_AGENT);
-        __hip_atomic_store(r + 1, s1, HJBX_RLX_AGENT);
-        __hip_atomic_store(r + 2, s2, HJBX_RLX_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record (and this wave's other stores) have left before the ticket is taken
-        const unsigned shard = blockIdx.x % kShards;
-        const unsigned in_shard = (gridDim.x - shard + kShards - 1) / kShards;          // workgroups with blockIdx % kShards == shard
-        unsigned* sc = cnt + shard * kShardStrideWords;
-        // the tickets are agent-scope RELEASE operations (paired with the acquire fence of the last arriver below): the ordering of
-        // record before ticket then holds by the memory model, not only by the explicit drain above
-        if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-            __hip_atomic_store(sc, 0u, HJBX_RLX_AGENT);                                 // every workgroup of this shard has arrived
-            unsigned* top = cnt + kShards * kShardStrideWords;
-            const unsigned nshards = gridDim.x < (unsigned)kShards ? gridDim.x : (unsigned)kShards;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                          // (the other workgroups' records of this shard)
-            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
-                __hip_atomic_store(top, 0u, HJBX_RLX_AGENT);
-                last = 1;
-            }
-        }
-    }
-    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double fa = 0, fb = 0, fc = 0;
-    for (unsigned r = lane; r < gridDim.x; r += 64) {      // records in index order per lane, then the fixed shuffle tree
-        fa += __hip_atomic_load(rec + 3 * (size_t)r + 0, HJBX_RLX_AGENT);
-        fb += __hip_atomic_load(rec + 3 * (size_t)r + 1, HJBX_RLX_AGENT);
-        fc += __hip_atomic_load(rec + 3 * (size_t)r + 2, HJBX_RLX_AGENT);
-    }
-    fa = wave_sum(fa); fb = wave_sum(fb); fc = wave_sum(fc);
-    if (lane == 0) { sums[0] = (T)fa; sums[1] = (T)fb; sums[2] = (T)fc; }
-}
-
-// hjb_loss body (vhjb.py:227-241) + analytic d loss_i / d gradV
 template <int MODE, int R, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_hjb_residual(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim,
                                                          const T* __restrict__ x, const T* __restrict__ g,
                                                          const T* __restrict__ done, T* __restrict__ loss_i,
                                                          T* __restrict__ dl_dg, unsigned char* ws, T* __restrict__ sums, int64_t B) {
-    constexpr int N = S::N;
-    // R rows in flight per thread (see k_simulate); the grid is capped at kReduceBlocks workgroups
-    double acc_l = 0, acc_nb = 0, acc_nd = 0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < B; i0 += R * stride) {
-        T xs[R][N], gs[R][N], dnv[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t i = i0 + r * stride;
-            if (i < B) {
-                RowIO<T, N>::load(x, i, xs[r]);
-                RowIO<T, N>::load(g, i, gs[r]);
-                dnv[r] = done[i];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t i = i0 + r * stride;
-            if (i < B) {
-                T out[N], li;
-                const T dn = dnv[r];
-                hjb_residual_env<MODE>(sys, tk, lim, xs[r], gs[r], dn, dl_dg != nullptr, li, out);
-                if (loss_i) loss_i[i] = li;
-                if (dl_dg) RowIO<T, N>::store(dl_dg, i, out);
-                acc_l += (double)li;
-                acc_nb += (double)(T(1) - dn);
-                acc_nd += (double)dn;
-            }
-        }
-    }
-    if (ws) block_sum3<T>(acc_l, acc_nb, acc_nd, ws, sums);
+    k_hjb_residual_body<MODE, R, S, T>(sys, tk, lim, x, g, done, loss_i, dl_dg, ws, sums, B);
 }
 
-// termination_loss body (vhjb.py:243-253)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_termination_residual(T eps, const T* __restrict__ V, const T* __restrict__ cost,
                                                                  const T* __restrict__ done, T* __restrict__ loss_i,
                                                                  T* __restrict__ dl_dV, unsigned char* ws, T* __restrict__ sums, int64_t B) {
-    double acc_l = 0, acc_nb = 0, acc_nd = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
-        const T dn = done[i];
-        T li, dv;
-        termination_residual_env<T>(eps, V[i], cost[i], dn, li, dv);
-        if (loss_i) loss_i[i] = li;
-        if (dl_dV) dl_dV[i] = dv;
-        acc_l += (double)li;
-        acc_nb += 1.0 - (double)dn;
-        acc_nd += (double)dn;
-    }
-    if (ws) block_sum3<T>(acc_l, acc_nb, acc_nd, ws, sums);
+    k_termination_residual_body<T>(eps, V, cost, done, loss_i, dl_dV, ws, sums, B);
 }
 
-// ----------------------------------------------------------------------------------------------
-// closed loop: one VHJB step given gradV, and whole rollouts under closed-form controllers
-// ----------------------------------------------------------------------------------------------
 template <int INTEG, int R, typename S, typename T>
 __global__ __launch_bounds__(kBlock) void k_vhjb_step(S sys, TaskP<T, S::N, S::M> tk, Limits<T, S::M> lim, int t, int T_max,
                                                       const T* x, const T* __restrict__ g, T* xn, T* __restrict__ u_out,
                                                       T* __restrict__ cost_t, T* __restrict__ done_t,
                                                       int32_t* __restrict__ done_step, T* __restrict__ resid_t, int64_t B) {
-    constexpr int N = S::N, M = S::M;
-    const int64_t base = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
-    T xs[R][N], gs[R][N];
-    int32_t dsv[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {   // (see k_simulate: all loads first)
-        const int64_t i = base + r * kBlock;
-        if (i < B) {
-            RowIO<T, N>::load(x, i, xs[r]);
-            RowIO<T, N>::load(g, i, gs[r]);
-            dsv[r] = done_step[i];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t i = base + r * kBlock;
-        if (i < B) {
-            T xo[N], u[M];
-            int32_t ds = dsv[r];
-            T c, d, res;
-            vhjb_step_env<INTEG>(sys, tk, lim, t, T_max, resid_t != nullptr, xs[r], gs[r], ds, xo, u, c, d, res);
-            if (ds != dsv[r]) done_step[i] = ds;
-            RowIO<T, N>::store(xn, i, xo);
-            if (u_out) RowIO<T, M>::store(u_out, i, u);
-            cost_t[i] = c;
-            done_t[i] = d;
-            if (resid_t) resid_t[i] = res;
-        }
-    }
+    k_vhjb_step_body<INTEG, R, S, T>(sys, tk, lim, t, T_max, x, g, xn, u_out, cost_t, done_t, done_step, resid_t, B);
 }
 
 template <int INTEG, int CK, typename S, typename T>
@@ -417,53 +152,44 @@ __global__ __launch_bounds__(kBlock) void k_rollout_feedback(S sys, TaskP<T, S::
                                                              T* __restrict__ u_log, T* __restrict__ cost,
                                                              int32_t* __restrict__ done_step, T* __restrict__ total_cost,
                                                              T* __restrict__ x_final, int64_t B) {
-    constexpr int N = S::N, M = S::M;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B) return;
-    T x[N], xn[N], u[M];
-    RowIO<T, N>::load(x0, i, x);
-    const bool term = (flags & HJBX_ROLLOUT_TERMINATE) != 0;
-    const bool stop_at_target = (flags & HJBX_ROLLOUT_STOP_AT_TARGET) != 0;
-    int ds = -1;
-    T tot = T(0);
-    for (int t = 0; t <= T_steps; ++t) {
-        if (traj) RowIO<T, N>::store(traj + (int64_t)t * B * N, i, x);
-        T cst = T(0);
-#pragma unroll
-        for (int j = 0; j < M; ++j) u[j] = T(0);
-        if (ds < 0) {
-            T e[N];
-            bool oob = false;
-            if (has_task) {
-                error_coords(sys, tk.xf, x, e);
-                oob = term && out_of_box<S, T>(tk, e);
-            }
-            bool reached = false;
-            if (stop_at_target) {  // cell 9 of the time-optimal notebook: `if x.T @ x <= metric: record t; break`
-                T d2 = T(0);
-#pragma unroll
-                for (int k = 0; k < N; ++k) d2 += (x[k] - c.xf[k]) * (x[k] - c.xf[k]);
-                reached = d2 <= c.eps_region;
-            }
-            if (t == T_steps || oob || reached) {
-                if (has_task && term && !reached) cst = quad_form<N>(tk.P, e);
-                ds = t;
-            } else {
-                controller_eval<CK>(sys, c, lim, x, u);
-                if (has_task) cst = running_cost_e<S, T>(tk, e, u) * lim.dt;
-                integrate<INTEG>(sys, lim.dt, x, u, xn);
-#pragma unroll
-                for (int k = 0; k < N; ++k) x[k] = xn[k];
-            }
-        }
-        tot += cst;
-        if (cost) cost[(int64_t)t * B + i] = cst;
-        if (u_log && t < T_steps) RowIO<T, M>::store(u_log + (int64_t)t * B * M, i, u);
-    }
-    if (done_step) done_step[i] = ds;
-    if (total_cost) total_cost[i] = tot;
-    if (x_final) RowIO<T, N>::store(x_final, i, x);
+    k_rollout_feedback_body<INTEG, CK, S, T>(sys, tk, c, lim, flags, has_task, T_steps, x0, traj, u_log, cost, done_step, total_cost, x_final, B);
 }
+
+// ----------------------------------------------------------------------------------------------
+// user-defined systems (HJBX_SYS_USER, hjbx_system_create_from_source): the same kernel bodies, compiled at run time for the user's struct
+// (hjbx_user.hip / hjbx_user_kernels.hpp).  Here: the typed kernel arguments for the handle's (n, m) and the launch by name.
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct UserBlob { T p[HJBX_USER_MAX_PARAMS]; };   // the kernel's first argument is `struct { T p[n_params]; }`
+template <typename T> static UserBlob<T> user_blob(const hjbx_system* s) {
+    UserBlob<T> b;
+    for (int i = 0; i < HJBX_USER_MAX_PARAMS; ++i) b.p[i] = i < s->n_params ? (T)s->p[i] : T(0);
+    return b;
+}
+template <int N_> struct DimsOnly { static constexpr int N = N_; };      // X0P<S, T> depends on S::N only
+template <typename T> struct UName {
+    char buf[64];
+    explicit UName(const char* base) { snprintf(buf, sizeof buf, "hjbx_u_%s_%s", base, sizeof(T) == 4 ? "f32" : "f64"); }
+    operator const char*() const { return buf; }
+};
+// calls f(integral_constant<int, n>, integral_constant<int, m>) for the handle's dimensions
+template <typename F> static int with_user_dims(const hjbx_system* s, F&& f) {
+#define HJBX_UD(NN)                                                              \
+    case NN:                                                                     \
+        if (s->m == 1) return f(std::integral_constant<int, NN>{}, std::integral_constant<int, 1>{}); \
+        if (s->m == 2) return f(std::integral_constant<int, NN>{}, std::integral_constant<int, 2>{}); \
+        if (s->m == 3) return f(std::integral_constant<int, NN>{}, std::integral_constant<int, 3>{}); \
+        break;
+    switch (s->n) { HJBX_UD(1) HJBX_UD(2) HJBX_UD(3) HJBX_UD(4) HJBX_UD(5) HJBX_UD(6) HJBX_UD(7) HJBX_UD(8) HJBX_UD(9) HJBX_UD(10) }
+#undef HJBX_UD
+    return hjbx_set_error(HJBX_EUNSUPPORTED, "user system with n=%d m=%d", s->n, s->m);
+}
+#define HJBX_USER(sys, ...) \
+    if ((sys)->kind == HJBX_SYS_USER) return with_user_dims(sys, [&](auto Nc, auto Mc) -> int { \
+        constexpr int N = decltype(Nc)::value, M = decltype(Mc)::value; (void)N; (void)M;      \
+        auto blob = user_blob<T>(sys);                                                         \
+        __VA_ARGS__                                                                            \
+    })
+static unsigned ugrid(int64_t B) { return (unsigned)((B + kBlock - 1) / kBlock); }
 
 // host side: descriptor conversion and dispatch live in hjbx_host.hpp (shared with hjbx_mlp.hip)
 
@@ -492,6 +218,7 @@ static bool aligned_rows(const void* p, size_t row_bytes) {
 // ---- typed implementations ---------------------------------------------------------------------
 template <typename T> static int affine_impl(const hjbx_system* sys, const T* x, T* f1, T* f2, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(f1, sys->n); HJBX_CHECK_ROWS(f2, sys->n * sys->m);
+    HJBX_USER(sys, void* a[] = {&blob, (void*)&x, (void*)&f1, (void*)&f2, (void*)&B}; return hjbx_user_launch(sys, UName<T>("affine"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             hipLaunchKernelGGL((k_affine<decltype(S), T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, x, f1, f2, B);
         })) return unsupported(sys);
@@ -500,6 +227,7 @@ template <typename T> static int affine_impl(const hjbx_system* sys, const T* x,
 
 template <typename T> static int wrap_impl(const hjbx_system* sys, const T* x, T* out, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(out, sys->n);
+    HJBX_USER(sys, void* a[] = {&blob, (void*)&x, (void*)&out, (void*)&B}; return hjbx_user_launch(sys, UName<T>("wrap"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             hipLaunchKernelGGL((k_wrap<decltype(S), T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, x, out, B);
         })) return unsupported(sys);
@@ -508,6 +236,7 @@ template <typename T> static int wrap_impl(const hjbx_system* sys, const T* x, T
 
 template <typename T> static int xdot_impl(const hjbx_system* sys, const T* x, const T* u, T* xd, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(xd, sys->n);
+    HJBX_USER(sys, void* a[] = {&blob, (void*)&x, (void*)&u, (void*)&xd, (void*)&B}; return hjbx_user_launch(sys, UName<T>("xdot"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             hipLaunchKernelGGL((k_xdot<decltype(S), T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S, x, u, xd, B);
         })) return unsupported(sys);
@@ -518,6 +247,8 @@ template <typename T>
 static int simulate_impl(const hjbx_system* sys, int integ, const T* x, const T* u, T* xn, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(xn, sys->n);
     if (int rc = check_integrator(sys, integ, "hjbx_simulate")) return rc;
+    HJBX_USER(sys, auto lim = make_limits<T, M>(sys); void* a[] = {&blob, &lim, (void*)&x, (void*)&u, (void*)&xn, (void*)&B};
+              return hjbx_user_launch(sys, UName<T>(integ == HJBX_RK4 ? "simulate_i1" : "simulate_i0"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto lim = make_limits<T, SS::M>(sys);
@@ -543,6 +274,8 @@ static int initial_state_impl(const hjbx_system* sys, const double* mean, const 
                               void* st) {
     HJBX_CHECK_COMMON(sys, B); HJBX_CHECK_ROWS(u01, sys->n); HJBX_CHECK_ROWS(x0, sys->n);
     HJBX_REQUIRE(mean && sd, "x0_mean / x0_std are NULL");
+    HJBX_USER(sys, X0P<DimsOnly<N>, T> p; for (int i = 0; i < N; ++i) { p.mean[i] = (T)mean[i]; p.std[i] = (T)sd[i]; }
+              void* a[] = {&blob, &p, (void*)&u01, (void*)&x0, (void*)&B}; return hjbx_user_launch(sys, UName<T>("initial_state"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             X0P<SS, T> p;
@@ -555,6 +288,8 @@ static int initial_state_impl(const hjbx_system* sys, const double* mean, const 
 template <typename T>
 static int running_cost_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, const T* u, T* cost, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc; HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m); HJBX_CHECK_ROWS(cost, 1);
+    HJBX_USER(sys, auto tk = make_task<T, N, M>(task); void* a[] = {&blob, &tk, (void*)&x, (void*)&u, (void*)&cost, (void*)&B};
+              return hjbx_user_launch(sys, UName<T>("running_cost"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             hipLaunchKernelGGL((k_running_cost<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
@@ -566,6 +301,8 @@ static int running_cost_impl(const hjbx_system* sys, const hjbx_task* task, cons
 template <typename T>
 static int termination_cost_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, T* cost, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc; HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(cost, 1);
+    HJBX_USER(sys, auto tk = make_task<T, N, M>(task); void* a[] = {&blob, &tk, (void*)&x, (void*)&cost, (void*)&B};
+              return hjbx_user_launch(sys, UName<T>("termination_cost"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             hipLaunchKernelGGL((k_termination_cost<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
@@ -577,6 +314,8 @@ static int termination_cost_impl(const hjbx_system* sys, const hjbx_task* task, 
 template <typename T>
 static int control_from_grad_impl(const hjbx_system* sys, const hjbx_task* task, const T* x, const T* g, T* u, int64_t B, void* st) {
     HJBX_CHECK_COMMON(sys, B); if (int rc = check_task(task)) return rc; HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(u, sys->m);
+    HJBX_USER(sys, auto tk = make_task<T, N, M>(task); auto lim = make_limits<T, M>(sys);
+              void* a[] = {&blob, &tk, &lim, (void*)&x, (void*)&g, (void*)&u, (void*)&B}; return hjbx_user_launch(sys, UName<T>("control_from_grad"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             hipLaunchKernelGGL((k_control_from_grad<SS, T>), grid_for(B), dim3(kBlock), 0, (hipStream_t)st, S,
@@ -608,6 +347,9 @@ static int hjb_residual_impl(const hjbx_system* sys, const hjbx_task* task, int 
     HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(done, 1); HJBX_CHECK_OPT(loss_i, 1); HJBX_CHECK_OPT(dl_dg, sys->n);
     const int grid = reduce_grid(B);
     unsigned char* ws = sums ? (unsigned char*)workspace : nullptr;
+    HJBX_USER(sys, auto tk = make_task<T, N, M>(task); auto lim = make_limits<T, M>(sys);
+              void* a[] = {&blob, &tk, &lim, (void*)&x, (void*)&g, (void*)&done, (void*)&loss_i, (void*)&dl_dg, (void*)&ws, (void*)&sums, (void*)&B};
+              return hjbx_user_launch(sys, UName<T>(mode == HJBX_RESIDUAL_RAW ? "hjb_residual_m1" : "hjb_residual_m0"), (unsigned)grid, a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto tk = make_task<T, SS::N, SS::M>(task);
@@ -657,6 +399,10 @@ static int vhjb_step_impl(const hjbx_system* sys, const hjbx_task* task, int int
     HJBX_REQUIRE(t >= 0 && T_max >= 0, "negative step index");
     HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(g, sys->n); HJBX_CHECK_ROWS(xn, sys->n); HJBX_CHECK_OPT(u_out, sys->m);
     HJBX_REQUIRE(cost_t && done_t && done_step, "cost_t/done_t/done_step must be non-NULL");
+    HJBX_USER(sys, auto tk = make_task<T, N, M>(task); auto lim = make_limits<T, M>(sys);
+              void* a[] = {&blob, &tk, &lim, (void*)&t, (void*)&T_max, (void*)&x, (void*)&g, (void*)&xn, (void*)&u_out, (void*)&cost_t, (void*)&done_t,
+                           (void*)&done_step, (void*)&resid_t, (void*)&B};
+              return hjbx_user_launch(sys, UName<T>(integ == HJBX_RK4 ? "vhjb_step_i1" : "vhjb_step_i0"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto tk = make_task<T, SS::N, SS::M>(task);
@@ -689,6 +435,8 @@ static int check_ctrl(const hjbx_system* sys, const hjbx_controller* c) {
     HJBX_REQUIRE(c->kind >= HJBX_CTRL_LINEAR_FEEDBACK && c->kind <= HJBX_CTRL_DI_TIME_OPTIMAL, "unknown controller kind %d", c->kind);
     if (c->kind == HJBX_CTRL_DI_TIME_OPTIMAL && !(sys->kind == HJBX_SYS_LINEAR && sys->n == 2 && sys->m == 1))
         return hjbx_set_error(HJBX_EINVAL, "the time-optimal bang-bang controller needs the double integrator (LINEAR, n=2, m=1)");
+    if (sys->kind == HJBX_SYS_USER && c->kind != HJBX_CTRL_LINEAR_FEEDBACK)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "user-defined systems take the linear feedback controller only");
     if (c->kind == HJBX_CTRL_CARTPOLE_ENERGY && sys->kind != HJBX_SYS_CARTPOLE)
         return hjbx_set_error(HJBX_EINVAL, "cartpole energy-shaping controller needs a cartpole system");
     if (c->kind == HJBX_CTRL_ACROBOT_ENERGY && sys->kind != HJBX_SYS_ACROBOT)
@@ -701,6 +449,8 @@ static int controller_impl(const hjbx_system* sys, const hjbx_controller* c, con
     HJBX_CHECK_COMMON(sys, B);
     if (int rc = check_ctrl(sys, c)) return rc;
     HJBX_CHECK_ROWS(x, sys->n); HJBX_CHECK_ROWS(u, sys->m);
+    HJBX_USER(sys, auto cp = make_ctrl<T, N, M>(c); auto lim = make_limits<T, M>(sys);
+              void* a[] = {&blob, &cp, &lim, (void*)&x, (void*)&u, (void*)&B}; return hjbx_user_launch(sys, UName<T>("controller"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             auto cp = make_ctrl<T, SS::N, SS::M>(c);
@@ -765,6 +515,11 @@ static int rollout_feedback_impl(const hjbx_system* sys, const hjbx_task* task, 
     if (task) { if (int rc = check_task(task)) return rc; }
     HJBX_REQUIRE(task || (!cost && !total_cost), "cost outputs need a task");
     HJBX_CHECK_ROWS(x0, sys->n); HJBX_CHECK_OPT(traj, sys->n); HJBX_CHECK_OPT(u_log, sys->m); HJBX_CHECK_OPT(x_final, sys->n);
+    HJBX_USER(sys, auto tk = make_task<T, N, M>(task); auto cp = make_ctrl<T, N, M>(c); auto lim = make_limits<T, M>(sys);
+              int has_task = task != nullptr;
+              void* a[] = {&blob, &tk, &cp, &lim, (void*)&flags, &has_task, (void*)&T_steps, (void*)&x0, (void*)&traj, (void*)&u_log, (void*)&cost,
+                           (void*)&done_step, (void*)&total_cost, (void*)&x_final, (void*)&B};
+              return hjbx_user_launch(sys, UName<T>(integ == HJBX_RK4 ? "rollout_feedback_i1" : "rollout_feedback_i0"), ugrid(B), a, st););
     if (!with_system<T>(sys, [&](auto S) {
             using SS = decltype(S);
             if (integ == HJBX_EULER)
@@ -846,7 +601,10 @@ int hjbx_system_create(int kind, int n, int m, double dt, const double* umin, co
     return HJBX_OK;
 }
 
-void hjbx_system_destroy(hjbx_system* sys) { delete sys; }
+void hjbx_system_destroy(hjbx_system* sys) {
+    if (sys && sys->user) hjbx_user_release(sys->user);
+    delete sys;
+}
 
 int hjbx_dims(const hjbx_system* sys, int* n, int* m) {
     HJBX_REQUIRE(sys && n && m, "NULL argument");

@@ -450,12 +450,12 @@ HJBX_DEV void hjb_residual_env(const S& sys, const TaskP<T, S::N, S::M>& tk, con
     error_coords(sys, tk.xf, xs, e);
     const T l = running_cost_e<S, T>(tk, e, u);
     const T den = l + tk.eps;
-    // float: one reciprocal per sample (the gradient below would otherwise need 2 divisions per state dimension);
-    // double keeps the reference's divisions in place (vhjb.py:233), like the dynamics structs above do
+    // The residual itself divides like the reference in both precisions (vhjb.py:233: one rounding; with a reciprocal the float32 loss
+    // was 2.3x further from the float64 oracle than the oracle's own float build, round 3).  float: one reciprocal per sample for the
+    // GRADIENT below (it would otherwise need 2 divisions per state dimension); double keeps every division in place.
     const T iden = T(1) / den;
     T r;
     if constexpr (MODE != 0) r = vdot + l;
-    else if constexpr (sizeof(T) == 4) r = vdot * iden + T(1);
     else r = vdot / den + T(1);
     const T w = T(1) - dn;
     li = abs_t(r) * w;

@@ -81,15 +81,32 @@ class Dynamics:
         if self._KIND is not None:
             self._sys = _abi.SystemHandle(self._KIND, self.state_dim, self.control_dim, self.dt, self.umin, self.umax,
                                           self._system_params(config))
+        else:
+            # a user-defined subclass (the reference lets any subclass define get_M / get_C / get_G / get_B and inherit
+            # get_control_affine_matrix, dynamics_basic.py:64-94): it hands the same per-state methods over as device code
+            src = self.device_source()
+            if src is not None:
+                kind = {"affine": _abi.USER_AFFINE, "manipulator": _abi.USER_MANIPULATOR}[src["kind"]]
+                self._sys = _abi.SystemHandle.from_source(kind, src["source"], self.state_dim, self.control_dim, self.dt, self.umin, self.umax,
+                                                          np.asarray(src.get("params", ()), np.float64))
 
     # -- subclass hooks ---------------------------------------------------------------------------
     def _system_params(self, config) -> np.ndarray:
         raise NotImplementedError
 
+    def device_source(self):
+        """Hook for user-defined subclasses: return dict(kind="manipulator" | "affine", source=<device code>, params=[...]) to get the
+        library's streaming kernels compiled for this system at run time (hjbx_system_create_from_source; contract of the snippet:
+        csrc/hjbx_user_kernels.hpp).  kind "manipulator": the snippet defines wrap, get_M, get_C, get_G, get_B and the generic
+        manipulator form of dynamics_basic.py:64-94 is supplied; kind "affine": it defines wrap and affine (f1, f2) itself.
+        Default: None -- such a subclass has no kernels and its compute methods raise NotImplementedError."""
+        return None
+
     @property
     def system(self) -> _abi.SystemHandle:
         if self._sys is None:
-            raise NotImplementedError(f"{type(self).__name__} has no device kernel (custom Dynamics subclasses need one)")
+            raise NotImplementedError(f"{type(self).__name__} has no device kernel: a custom Dynamics subclass gets its kernels by defining "
+                                      "device_source() (see Dynamics.device_source)")
         return self._sys
 
     # -- reference API ----------------------------------------------------------------------------

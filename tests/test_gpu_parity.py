@@ -50,7 +50,7 @@ def task_for(name, d):
 @pytest.mark.parametrize("name", SYSTEMS)
 def test_pointwise_kernels(name, prec):
     tdt, ndt, tol = DT[prec]
-    d, x, u = sample_states(name, 1000, seed=1)   # ragged: not a multiple of the 256-thread block
+    d, x, u = sample_states(name, 20001, seed=1)   # ragged: not a multiple of the 256-thread block; large enough for stable max / p99.9 statistics
     s = orc_system(name)
     xd, ud = dev(x, tdt), dev(u, tdt)
     xr, ur = xd.cpu().numpy().astype(np.float64), ud.cpu().numpy().astype(np.float64)  # oracle sees the rounded inputs
@@ -141,7 +141,7 @@ def test_dynamics_surface_numpy_roundtrip(name):
 @pytest.mark.parametrize("name", SYSTEMS)
 def test_hjb_residual(name, mode, prec):
     tdt, ndt, tol = DT[prec]
-    d, x, _ = sample_states(name, 777, seed=5)
+    d, x, _ = sample_states(name, 20077, seed=5)      # ragged, and large enough for the max / p99.9 statistics of the yardstick to be stable
     s = orc_system(name)
     task = task_for(name, d)
     rng = np.random.default_rng(11)
@@ -296,7 +296,7 @@ def test_rollout_feedback_vs_oracle(name, prec):
     n, m = d.get_dimension()
     task = _abi.make_task(n, m, cfg.Q, cfg.R, np.eye(n) * 2.0, c.xf if hasattr(c, "xf") else cfg.xf, getattr(c, "uf", cfg.uf), cfg.obs_min,
                           cfg.obs_max, cfg.epsilon)
-    B, T = 300, 60
+    B, T = 3001, 60
     rng = np.random.default_rng(21)
     xf = np.asarray(c.xf if hasattr(c, "xf") else cfg.xf, np.float64)
     x0 = xf + rng.uniform(-1, 1, (B, n)) * np.asarray(cfg.obs_max, np.float64).clip(max=3.0) * 0.9
@@ -383,7 +383,7 @@ def test_vhjb_step_sequence(name, prec):
     task = _abi.make_task(n, m, cfg.Q, cfg.R, np.eye(n) * 3.0, cfg.xf, cfg.uf, cfg.obs_min, cfg.obs_max, cfg.epsilon)
     import types
     tk = types.SimpleNamespace(R=cfg.R, R_inv=np.linalg.inv(np.asarray(cfg.R, np.float64)), uf=cfg.uf, epsilon=cfg.epsilon)
-    B, T = 513, 12
+    B, T = 20001, 12
     rng = np.random.default_rng(33)
     xf = np.asarray(cfg.xf, np.float64)
     x = xf + rng.uniform(-1.05, 1.05, (B, n)) * np.asarray(cfg.obs_max, np.float64).clip(max=3.0)   # ~some start outside the box

@@ -212,8 +212,12 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_reduction_equals_single_process(tmp_path):
-    """G-rank result == 1-rank result on the same global minibatch (SURVEY 8e acceptance), gloo, world 2."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_data_parallel_reduction_equals_single_process(tmp_path, world):
+    """G-rank result == 1-rank result on the same global minibatch (SURVEY 8e acceptance), gloo, world 2 / 4 / 8, UNEVEN shards.  From world 4
+    on, one rank holds only interior samples (zero `done`: its termination sums and count are 0) and one rank only terminal ones (zero live
+    samples: its hjb sums and count are 0) -- per-rank means would divide by zero / be wrong there; the flat buffer carries SUMS and counts
+    and the division by the global counts happens after the ONE all-reduce (reference normalisers: controller/vhjb.py:241, 253)."""
     import torch.multiprocessing as mp
     from q_learning_with_hjb_amd.controller.vhjb import allreduce_and_mix
     torch.manual_seed(0)
@@ -222,8 +226,12 @@ def test_data_parallel_reduction_equals_single_process(tmp_path):
     xs = torch.as_tensor(np.array([0, 3.1415926, 0, 0]) + rng.uniform(-1, 1, (B, 4)) * [1.0, 0.3, 1.0, 1.0])
     dones = torch.as_tensor((rng.uniform(size=B) < np.linspace(0.05, 0.7, B)).astype(np.float64))   # done density differs per shard
     costs = torch.as_tensor(rng.uniform(0.5, 9.0, B))
+    cuts = {2: [0, 37, B], 4: [0, 30, 41, 70, B], 8: [0, 9, 20, 33, 41, 58, 70, 83, B]}[world]
+    if world >= 4:
+        dones[cuts[1]:cuts[2]] = 0.0                 # rank 1: no terminal sample at all
+        dones[cuts[2]:cuts[3]] = 1.0                 # rank 2: no live sample at all
     W = [torch.randn(4, 16, dtype=torch.float64) * 0.5, torch.randn(16, 16, dtype=torch.float64) * 0.3, torch.randn(16, 8, dtype=torch.float64) * 0.3]
-    torch.save(dict(xs=xs, dones=dones, costs=costs, W=W, splits=[0, 37, B]), tmp_path / "dp.pt")
+    torch.save(dict(xs=xs, dones=dones, costs=costs, W=W, splits=cuts), tmp_path / "dp.pt")
     os.environ["HJBX_TEST_TMP"] = str(tmp_path)
     # single process on the whole minibatch
     Ws = [w.clone().requires_grad_(True) for w in W]
@@ -232,13 +240,13 @@ def test_data_parallel_reduction_equals_single_process(tmp_path):
     want, whl, wtl = allreduce_and_mix(g_h, g_t, (hs.detach(), ts.detach(), ni, nd), Ws, 0.25, 1e-10, False)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, hl, tl = q.get(timeout=120)
+    got, hl, tl = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert abs(hl - float(whl)) < 1e-12 and abs(tl - float(wtl)) < 1e-12
     for a, b in zip(got, want):
@@ -318,7 +326,7 @@ def test_bench_self_launches_n_ranks():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["rank_sum"] == 3 and line["steps"] == 7 and line["scaling"] == "strong"
+    assert line["n_gpus"] == 2 and line["rank_sum"] == 3 and line["ranks_seen"] == 2 and line["steps"] == 7 and line["scaling"] == "strong"
     assert line["shards"] == [[0, 1 << 19], [1 << 19, 1 << 20]] and line["global_batch"] == 1 << 20
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
