@@ -129,7 +129,11 @@ typedef enum hjbx_option {
                                               Modes 1 and 2 are faster and narrower than the reference's arithmetic: never the default.
                                               tests/test_gpu_f32_parity.py runs every test in every mode against the same bounds, and
                                               test_fused_value_grad_split_arithmetics_stay_within_their_stated_bound checks modes 1 / 2 against
-                                              mode 0 on the device. */
+                                              mode 0 on the device. */,
+    HJBX_OPT_TRAIN_KERNEL = 4              /* implementation of hjbx_value_loss_grad_f32 in the float32 arithmetic (results agree to float32 summation
+                                              order): 0 (default) = the cooperative single kernel (no scratch in HBM, a tile's chains split over the four
+                                              waves of a workgroup, ReLU and tanh); 1 = the round-2 pair of kernels (chains + outer products through a
+                                              5-KB-per-sample scratch; ReLU only) -- kept for A/B measurements and for the f16x2 arithmetic */
 } hjbx_option;
 
 typedef struct hjbx_system hjbx_system; /* opaque */
@@ -329,9 +333,9 @@ int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const h
  * i.e. the gradients of the loss SUMS (the caller divides by the counts, vhjb.py:241, 253, and mixes with the regularisation weight,
  * :284) -- the buffer a data-parallel step all-reduces once.  hjb_loss is a function of dV/dx, so its gradient is a second-order
  * reverse sweep; both are evaluated in closed form (no autograd graph).  `mode` = hjbx_residual_mode.  Deterministic: no float atomics,
- * fixed summation order (the order depends on B and the device's CU count only).  ReLU networks with features [128,128,64] only
- * (HJBX_EUNSUPPORTED otherwise: the PyTorch autograd path remains).  workspace: hjbx_value_loss_grad_workspace_bytes(B) bytes, 256-byte
- * aligned, need not be initialised. */
+ * fixed summation order (the order depends on B and the device's CU count only).  ReLU and tanh networks with features [128,128,64]
+ * (HJBX_EUNSUPPORTED otherwise: the PyTorch autograd path remains).  workspace: hjbx_value_loss_grad_workspace_bytes(B) bytes (it depends on
+ * HJBX_OPT_MLP_ARITHMETIC / HJBX_OPT_TRAIN_KERNEL: ask again after changing them), 256-byte aligned, need not be initialised. */
 size_t hjbx_value_loss_grad_workspace_bytes(int64_t B);
 int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
                              const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream);

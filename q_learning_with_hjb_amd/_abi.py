@@ -26,7 +26,7 @@ LAW_QUADRATIC, LAW_BANGBANG = 0, 1
 ACT_RELU, ACT_TANH, ACT_SIN = 0, 1, 2
 ROLLOUT_TERMINATE = 1
 ROLLOUT_STOP_AT_TARGET = 2
-OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS, OPT_STREAM_ROWS, OPT_MLP_ARITHMETIC = 0, 1, 2, 3
+OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS, OPT_STREAM_ROWS, OPT_MLP_ARITHMETIC, OPT_TRAIN_KERNEL = 0, 1, 2, 3, 4
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -38,6 +38,7 @@ _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=2",), "hjbx_mlp_x3.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=3", "-fno-slp-vectorize"), "hjbx_mlp_h2.o"),
           ("hjbx_train.hip", ("-fno-slp-vectorize",), "hjbx_train.o"),
+          ("hjbx_train_coop.hip", ("-fno-slp-vectorize",), "hjbx_train_coop.o"),
           ("hjbx_user.hip", (f'-DHJBX_CSRC_DIR="{_CSRC}"',), "hjbx_user.o"))       # embeds three headers as text for hiprtc (.incbin)
 _SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
 _HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", "hjbx_mlp_x3.hpp", "hjbx_mlp_h2.hpp", "hjbx_stream_kernels.hpp",

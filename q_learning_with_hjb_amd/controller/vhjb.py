@@ -300,14 +300,15 @@ class VHJBController(Controller):
         if self.fused_value_grad and not fusable:
             raise NotImplementedError(f"no fused value-gradient kernel for the {activation} activation")
         # the parameter gradient of the optimiser step: hand-written MFMA kernels (hjbx_value_loss_grad_f32: forward, input gradient,
-        # residuals and the second-order reverse sweep in closed form) for the float32 ReLU network of controller/vhjb.py; anything else
-        # (float64, tanh / sin, HJBX_FUSED_PARAM_GRAD=0) goes through PyTorch autograd
-        can_fuse_pg = (dtype == torch.float32 and activation == "relu" and tuple(config.features) == (128, 128, 64) and self.device.type == "cuda"
+        # residuals and the second-order reverse sweep in closed form) for the float32 ReLU network of controller/vhjb.py and the tanh network
+        # of examples/cartpole_balancing.ipynb; anything else (float64, sin, HJBX_FUSED_PARAM_GRAD=0) goes through PyTorch autograd
+        can_fuse_pg = (dtype == torch.float32 and activation in ("relu", "tanh") and tuple(config.features) == (128, 128, 64) and self.device.type == "cuda"
                        and not config.using_batch_norm and builtin)
         if fused_param_grad is None:
             fused_param_grad = can_fuse_pg and os.environ.get("HJBX_FUSED_PARAM_GRAD", "1") != "0"
         if fused_param_grad and not can_fuse_pg:
-            raise NotImplementedError("the fused parameter-gradient kernels exist for the float32 ReLU network with features [128, 128, 64] only")
+            raise NotImplementedError("the fused parameter-gradient kernels exist for float32 ReLU / tanh networks with features [128, 128, 64] on the "
+                                      "built-in systems only")
         self.fused_param_grad = bool(fused_param_grad)
         # fused rollouts of big batches re-pack live environments every `compaction_interval` steps (0 = never)
         self.compaction_interval, self.compaction_min_batch = 16, 8192

@@ -36,8 +36,8 @@ int hjbx_set_error(int code, const char* fmt, ...) {
 }
 
 // process-wide knobs (include/hjbx.h: hjbx_option)
-static std::atomic<int> g_options[4] = {{0}, {0}, {0}, {0}};   // (HJBX_OPT_MLP_ARITHMETIC defaults to 0 = float32 MFMA, the reference's arithmetic)
-int hjbx_option_value(int option) { return (option >= 0 && option < 4) ? g_options[option].load(std::memory_order_relaxed) : 0; }
+static std::atomic<int> g_options[5] = {{0}, {0}, {0}, {0}, {0}};   // (HJBX_OPT_MLP_ARITHMETIC defaults to 0 = float32 MFMA, the reference's arithmetic)
+int hjbx_option_value(int option) { return (option >= 0 && option < 5) ? g_options[option].load(std::memory_order_relaxed) : 0; }
 
 #define HJBX_REQUIRE(cond, ...)                                  \
     do {                                                         \
@@ -561,7 +561,8 @@ int hjbx_device_count(void) {
 }
 
 int hjbx_set_option(int option, int value) {
-    HJBX_REQUIRE(option == HJBX_OPT_ROLLOUT_SCHEDULE || option == HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS || option == HJBX_OPT_STREAM_ROWS || option == HJBX_OPT_MLP_ARITHMETIC, "unknown option %d", option);
+    HJBX_REQUIRE(option == HJBX_OPT_ROLLOUT_SCHEDULE || option == HJBX_OPT_ROLLOUT_EXTRA_WORKGROUPS || option == HJBX_OPT_STREAM_ROWS || option == HJBX_OPT_MLP_ARITHMETIC || option == HJBX_OPT_TRAIN_KERNEL, "unknown option %d", option);
+    HJBX_REQUIRE(option != HJBX_OPT_TRAIN_KERNEL || value <= 1, "train kernel must be 0 (cooperative single kernel) or 1 (the round-2 pair), got %d", value);
     HJBX_REQUIRE(option != HJBX_OPT_MLP_ARITHMETIC || value <= 2, "mlp arithmetic must be 0 (f32 MFMA), 1 (bf16x3-split MFMA) or 2 (f16x2-split MFMA), got %d", value);
     HJBX_REQUIRE(option != HJBX_OPT_ROLLOUT_SCHEDULE || value <= 1, "rollout schedule must be 0 or 1, got %d", value);
     HJBX_REQUIRE(value <= 64, "option value %d out of range", value);

@@ -238,14 +238,15 @@ template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, uns
         const unsigned shard = blockIdx.x % kShards;
         const unsigned in_shard = (gridDim.x - shard + kShards - 1) / kShards;          // workgroups with blockIdx % kShards == shard
         unsigned* sc = cnt + shard * kShardStrideWords;
-        // the tickets are agent-scope RELEASE operations (paired with the acquire fence of the last arriver below): the ordering of
-        // record before ticket then holds by the memory model, not only by the explicit drain above
-        if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+        // The tickets stay RELAXED agent-scope atomics behind the explicit drain above (guide 6 G16, R1 form: write-through record
+        // stores + s_waitcnt vmcnt(0) + returning atomic).  Round 3 tried __ATOMIC_RELEASE tickets + an acquire fence per shard:
+        // a release at agent scope is a buffer_wbl2 of the L2, which here holds the 16-52 MB of loss_i / dloss_dgrad the kernel has just
+        // written -- the cartpole entry point went 18.1 -> 40.5 us at B = 2^20 (gpurun_out/r03_bench1.json).  Reverted.
+        if (__hip_atomic_fetch_add(sc, 1u, HJBX_RLX_AGENT) == in_shard - 1) {
             __hip_atomic_store(sc, 0u, HJBX_RLX_AGENT);                                 // every workgroup of this shard has arrived
             unsigned* top = cnt + kShards * kShardStrideWords;
             const unsigned nshards = gridDim.x < (unsigned)kShards ? gridDim.x : (unsigned)kShards;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                          // (the other workgroups' records of this shard)
-            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nshards - 1) {
+            if (__hip_atomic_fetch_add(top, 1u, HJBX_RLX_AGENT) == nshards - 1) {
                 __hip_atomic_store(top, 0u, HJBX_RLX_AGENT);
                 last = 1;
             }

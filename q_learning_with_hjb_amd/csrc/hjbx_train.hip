@@ -638,7 +638,20 @@ static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, c
     }
 }
 
-extern "C" size_t hjbx_value_loss_grad_workspace_bytes(int64_t B) { return B > 0 ? train_ws(B).total : 0; }
+// which implementation a call takes: the cooperative single kernel (hjbx_train_coop.hip: float32 MFMA, ReLU and tanh, no scratch) unless the
+// f16x2 value-network arithmetic is selected (its split-operand chains live in the round-2 pair of kernels below) or HJBX_OPT_TRAIN_KERNEL = 1
+// asks for that pair (A/B measurements); tanh networks exist in the cooperative kernel only
+static bool use_two_kernels(int activation) {
+    if (activation == HJBX_ACT_TANH) return false;
+    return hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 2 || hjbx_option_value(HJBX_OPT_TRAIN_KERNEL) == 1;
+}
+
+extern "C" size_t hjbx_value_loss_grad_workspace_bytes(int64_t B) {
+    if (B <= 0) return 0;
+    const size_t coop = hjbx_train_coop_workspace_bytes(B, HJBX_MAX_N);
+    const size_t pair = use_two_kernels(HJBX_ACT_RELU) ? train_ws(B).total : 0;
+    return coop > pair ? coop : pair;
+}
 
 extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
                                         const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream) {
@@ -657,14 +670,16 @@ extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task*
         return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x, cost, done, workspace and the weights must be non-NULL");
     if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2, mlp->h3);
-    if (mlp->activation != HJBX_ACT_RELU)
-        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: the fused parameter-gradient kernels exist for the relu network (controller/vhjb.py) only");
+    if (mlp->activation != HJBX_ACT_RELU && mlp->activation != HJBX_ACT_TANH)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: the fused parameter-gradient kernels exist for relu (controller/vhjb.py) and tanh "
+                                                 "(examples/cartpole_balancing.ipynb) networks; sin goes through autograd");
     const size_t row = (size_t)sys->n * sizeof(float);
     const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
     if ((reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x must be aligned to its row vector width and workspace to 256 bytes");
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: normalization_std[%d] is zero", k);
+    if (!use_two_kernels(mlp->activation)) return hjbx_train_coop(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
     int rc = HJBX_EUNSUPPORTED;
 #ifdef HJBX_TRAIN_DEV   // development builds: cartpole only (the full set of instantiations takes minutes to compile)
     bool ok = false;

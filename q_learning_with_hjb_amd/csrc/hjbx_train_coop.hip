@@ -1,0 +1,563 @@
+// hjbx_train_coop.hip -- the parameter gradient of the value-learning step (reference controller/vhjb.py:227-253, 282-284) in ONE kernel with
+// NO scratch in HBM (round 3; hjbx_train.hip holds the round-2 pair of kernels, which moved 10 KB per sample through HBM and walked a tile's
+// 1,552 MFMAs on one wave).  ReLU (controller/vhjb.py) and tanh (examples/cartpole_balancing.ipynb cell 6) networks, float32 MFMA.
+//
+// Math per sample (s = act'(a); ReLU: act'' = 0, tanh: act'' = -2 h s), q = d loss_hjb / d gradV, r = d loss_term / d V:
+//   forward            h1 = act(W1'z)   h2 = act(W2'h1)   y = W3'h2   V = |y|^2 + eps_s |e|^2
+//   input gradient     dy = 2y   d2 = (W3 dy).s2   d1 = (W2 d2).s1   g = (W1 d1)/std + 2 eps_s e
+//   reverse sweep (q)  gzb = q/std   t1 = W1'gzb   dh1b = t1.s1   t2 = W2'dh1b   dh2b = t2.s2   yb = 2 W3'dh2b
+//                      a2b = (W3 yb).s2 - 2 h2.d2.t2 [tanh]      a1b = (W2 a2b).s1 - 2 h1.d1.t1 [tanh]
+//   hjb gradient       dW1 = gzb (x) d1 + z (x) a1b      dW2 = dh1b (x) d2 + h1 (x) a2b      dW3 = dh2b (x) dy + h2 (x) yb
+//   termination grad.  dW1 = z (x) (r d1)                dW2 = h1 (x) (r d2)                 dW3 = h2 (x) (r dy)
+// (the second-order terms of tanh: the adjoint of s = 1 - h^2 is (adjoint of d).(W d_next) and d s / d a = -2 h s, so a_bar gains
+//  -2 h . d . t with t the pre-mask value of the reverse sweep.)
+//
+// Design.  A workgroup = 4 waves = one wave per SIMD with 512 registers; it works on ONE 32-sample tile at a time, COOPERATIVELY:
+//  * every 128-wide array (h1, h2, d2, d1, ...) is split by 32-feature block over the four waves, so a product W'X is 64 k-steps of ONE
+//    MFMA per wave instead of 256 MFMAs on one wave (latency of a tile / 4: what the reference's minibatch of 256 = 8 tiles needs), and
+//    each wave keeps its blocks of h1, h2, dy, d1 (and the tanh corrections) in registers across the whole tile;
+//  * a product needs all 128 input features as B operands, so each result block goes through a [feature][sample] image in LDS (stride 33:
+//    conflict-free for the column-wise write, the chain's B read and the outer products' A / B reads alike).  Those images ARE the
+//    transposition the outer products need (their contraction index is the sample): no scratch, no second kernel.  Three 16.5-KiB
+//    images suffice; h1, h2, dy are written again from registers when their partner of an outer product arrives;
+//  * the 48 32x32 output blocks of dW2 / dW3 (hjb + termination sets) are MFMA accumulators for the whole launch, 12 per wave (row block
+//    w of dW2 and of dW3: their A operands are shared); dW1 (n x 128: 3 % of the flops) is accumulated on the VALU, one feature per thread;
+//  * y = W3'h2 has only two 32-row blocks: its contraction is split in halves over wave pairs and summed through LDS, so all four matrix
+//    pipes work in every phase.  g = W1 d1 is a 16-k-step MFMA per wave over its own block (B operands straight from the accumulators) +
+//    an LDS sum; every wave then evaluates the two residuals for its sample redundantly (same bits) instead of waiting for one.
+// LDS: weights 102-104 KB (f32, odd strides, one copy for W and W') + 3 x 16.5 KB images + 5 KB small = 157 KB (n = 10).
+// Per tile and wave: 394 chain MFMAs + 336 outer-product MFMAs; HBM traffic = the inputs (4(n+2) B per sample) + the partial sums.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "hjbx_internal.hpp"
+#include "hjbx_systems.hpp"
+#include "hjbx_host.hpp"
+#include "hjbx_mlp_core.hpp"
+
+using namespace hjbx;
+
+static constexpr int kExLd = 33;                      // row stride of an exchange image (floats)
+static constexpr int kExFloats = 128 * kExLd;
+static constexpr int kCoopBlocks = 48;                // per set 24: dW2 (ib, jb) -> ib * 4 + jb; dW3 (ib, jb) -> 16 + ib * 2 + jb
+static constexpr int kCoopSet = 24;
+
+template <int N> struct CoopLds {
+    static constexpr int NP = (N + 3) & ~3;
+    float W1[N * kLD1];
+    float W2[kH1 * kLD2];
+    float W3[kH2 * kLD3];
+    float E[3][kExFloats];
+    __attribute__((aligned(16))) float zs[32 * NP];    // [sample][k]: z, zero padded to NP
+    __attribute__((aligned(16))) float gzbs[32 * NP];  // [sample][k]: q / std
+    float rs[32];                                      // r = d loss_term / d V per sample
+    float vp[2][32];                                   // |y|^2 partial sums of the two 32-row blocks of y
+    float zeros[32];                                   // A operand of the lanes that stand for rows >= n of W1 (g product)
+};
+
+// ---- a chain whose A (weights) AND B (an exchange image) operands both come from LDS ------------------------------------------------
+// Same discipline as mfma_chain (hjbx_mlp_core.hpp): inline-asm ds_reads DEPTH steps ahead, retired by counted s_waitcnt lgkmcnt, so
+// that a step is 2 reads + 1 wait + 1 MFMA and hipcc cannot sink the reads to their use.  AOFF / BOFF: byte offset of step st from the
+// lane-dependent bases (compile-time constants).
+template <int AOFF, int BOFF, int ST> __device__ __forceinline__ void coop_issue(float& a, float& b, uint32_t abase, uint32_t bbase) {
+    a = lds_read_b32<AOFF * ST>(abase);
+    b = lds_read_b32<BOFF * ST>(bbase);
+}
+template <int AOFF, int BOFF, int NSTEPS, int DEPTH, int ST>
+__device__ __forceinline__ void coop_chain_step(f32x16& acc, float (&ra)[DEPTH + 1], float (&rb)[DEPTH + 1], uint32_t abase, uint32_t bbase) {
+    if constexpr (ST < NSTEPS) {
+        if constexpr (ST + DEPTH < NSTEPS) coop_issue<AOFF, BOFF, ST + DEPTH>(ra[(ST + DEPTH) % (DEPTH + 1)], rb[(ST + DEPTH) % (DEPTH + 1)], abase, bbase);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int ahead = (NSTEPS - 1 - ST < DEPTH ? NSTEPS - 1 - ST : DEPTH) * 2;
+        lds_wait<ahead>();
+        acc = MFMA(ra[ST % (DEPTH + 1)], rb[ST % (DEPTH + 1)], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        coop_chain_step<AOFF, BOFF, NSTEPS, DEPTH, ST + 1>(acc, ra, rb, abase, bbase);
+    }
+}
+template <int AOFF, int BOFF, int NSTEPS> __device__ __forceinline__ void coop_chain(f32x16& acc, uint32_t abase, uint32_t bbase) {
+    constexpr int DEPTH = 3;
+    static_assert(AOFF * (NSTEPS - 1) < 65536 && BOFF * (NSTEPS - 1) < 65536, "ds_read_b32 offset field is 16 bits");
+    float ra[DEPTH + 1], rb[DEPTH + 1];
+    coop_issue<AOFF, BOFF, 0>(ra[0], rb[0], abase, bbase);
+    if constexpr (NSTEPS > 1) coop_issue<AOFF, BOFF, 1>(ra[1], rb[1], abase, bbase);
+    if constexpr (NSTEPS > 2) coop_issue<AOFF, BOFF, 2>(ra[2], rb[2], abase, bbase);
+    coop_chain_step<AOFF, BOFF, NSTEPS, DEPTH, 0>(acc, ra, rb, abase, bbase);
+}
+
+// A operands of the two products whose B operands are registers (mfma_chain of hjbx_mlp_core.hpp, one output block)
+struct OffW1Fc { static constexpr int at(int st, int) { return 2 * st * kLD1 * 4; } };   // W1[2 st + h][32 w + i]
+struct OffW1Gc { static constexpr int at(int st, int) { return perm(st) * 4; } };        // W1[i][32 w + perm(st) + 4 h]
+
+// 32-bit pointers into LDS: address arithmetic on them stays `ds_read_b32 v, vaddr offset:constant`.  Inside the tile loop every lane base
+// is re-derived from an OPAQUE copy of the image pointers (opaque3): left alone, hipcc hoists the ~200 loop-invariant `base + constant`
+// addresses of the outer products out of the tile loop, keeps them in registers for the whole kernel and spills them (78 dwords of scratch
+// in the first build of this kernel; the same trap as the XOR-swizzled bases of hjbx_mlp_h2.hpp).
+using LP = __attribute__((address_space(3))) float*;
+using LPc = const __attribute__((address_space(3))) float*;
+__device__ __forceinline__ uint32_t lds_addr(LPc q) { return (uint32_t)(uintptr_t)q; }
+
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// this lane's 16 accumulator values (rows perm(r) + 4 h of its wave's 32-row block, column = sample i) into / out of a [feature][sample] image
+__device__ __forceinline__ void ex_write(LP blk /* &E[(32 w + 4 h) * kExLd + i] */, const f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk[perm(r) * kExLd] = v[r];
+}
+__device__ __forceinline__ void ex_add(f32x16& v, LPc blk) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += blk[perm(r) * kExLd];
+}
+
+// Outer products of one 32-sample tile: acch[j] += A_h (x) B_h,j and acct[j] += A_t (x) (r B_t,j) over the 16 k-steps (2 samples each).
+// A = rows 32 w + i of an image (exA = (32 w + i) kExLd + h), B_j = rows 32 j + i of another (exBj = i kExLd + h), rs = r per sample.
+template <int NB, bool HJB, bool TERM>
+__device__ __forceinline__ void coop_outer(f32x16 (&acch)[NB], LPc Ah, LPc Bh, f32x16 (&acct)[NB], LPc At, LPc Bt, LPc rs, int exA, int exBj, int h) {
+    LPc ah_p = Ah + exA, bh_p = Bh + exBj, at_p = At + exA, bt_p = Bt + exBj, r_p = rs + h;   // lane bases; everything below is base + constant
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float ah = 0.f, at = 0.f, rr = 0.f;
+        if constexpr (HJB) ah = ah_p[2 * s];
+        if constexpr (TERM) { at = at_p[2 * s]; rr = r_p[2 * s]; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (HJB) acch[j] = MFMA(ah, bh_p[32 * j * kExLd + 2 * s], acch[j]);
+            if constexpr (TERM) acct[j] = MFMA(at, rr * bt_p[32 * j * kExLd + 2 * s], acct[j]);
+        }
+    }
+}
+
+template <int MODE, int ACT, typename S>
+__global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k, Limits<float, S::M> lim_k,
+                                                       const float* __restrict__ W1g, const float* __restrict__ W2g, const float* __restrict__ W3g,
+                                                       const float* __restrict__ x, const float* __restrict__ cost, const float* __restrict__ done,
+                                                       float eps_term, float* __restrict__ partial, float* __restrict__ partial_w1,
+                                                       double* __restrict__ sums_rec, int64_t B, int64_t ntiles) {
+    constexpr int N = S::N, M = S::M;
+    constexpr int NP = CoopLds<N>::NP;
+    static_assert(N % 2 == 0 && N <= HJBX_MAX_N, "state dimension");
+    __shared__ __attribute__((aligned(256))) CoopLds<N> L;
+    __shared__ __attribute__((aligned(16))) unsigned char sys_raw[sizeof(S)];
+    S& sys_s = *reinterpret_cast<S*>(sys_raw);
+    __shared__ MlpP<N> p_s;
+    __shared__ TaskP<float, N, M> tk_s;
+    __shared__ Limits<float, M> lim_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) { sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k; }
+    for (int idx = tid; idx < N * kH1; idx += 256) L.W1[(idx / kH1) * kLD1 + (idx % kH1)] = W1g[idx];
+    for (int idx = tid; idx < kH1 * kH2; idx += 256) L.W2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
+    for (int idx = tid; idx < kH2 * kH3; idx += 256) L.W3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
+    if (tid < 32) L.zeros[tid] = 0.f;
+    for (int idx = tid; idx < 32 * NP; idx += 256) { L.zs[idx] = 0.f; L.gzbs[idx] = 0.f; }
+    __syncthreads();
+    const S& sys = sys_s;
+    const MlpP<N>& p = p_s;
+    const TaskP<float, N, M>& tk = tk_s;
+    const Limits<float, M>& lim = lim_s;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ob = w & 1, kh = w >> 1;                 // y = W3'h2: output block and contraction half of this wave
+    // LDS byte addresses (the low 32 bits of a flat pointer into the LDS aperture are the LDS byte address)
+    auto lds = [](const void* q) { return (uint32_t)(uintptr_t)q; };
+    auto lds3 = [](LPc q) { return lds_addr(q); };
+    const uint32_t aW1f = lds(&L.W1[h * kLD1 + 32 * w + i]);                       // W1[2 st + h][32 w + i]
+    const uint32_t aW1g = i < N ? lds(&L.W1[i * kLD1 + 32 * w + 4 * h]) : lds(&L.zeros[0]);   // W1[i][32 w + perm(st) + 4 h], rows >= n read zeros
+    const uint32_t aW2f = lds(&L.W2[h * kLD2 + 32 * w + i]);                       // W2[2 st + h][32 w + i]
+    const uint32_t aW2b = lds(&L.W2[(32 * w + i) * kLD2 + h]);                     // W2[32 w + i][2 st + h]
+    const uint32_t aW3f = lds(&L.W3[(64 * kh + h) * kLD3 + 32 * ob + i]);          // W3[64 kh + 2 st + h][32 ob + i]
+    const uint32_t aW3b = lds(&L.W3[(32 * w + i) * kLD3 + h]);                     // W3[32 w + i][2 st + h]
+    const LP E0g = (LP)&L.E[0][0], E1g = (LP)&L.E[1][0], E2g = (LP)&L.E[2][0];
+    const LP rsg = (LP)&L.rs[0], zsg = (LP)&L.zs[0], gzbsg = (LP)&L.gzbs[0];
+    const int exB = h * kExLd + i;                     // B operand of step st: image[(2 st + h)][i]
+    const int exW = (32 * w + 4 * h) * kExLd + i;      // this lane's writes of its wave's 128-wide block
+    const int exWy = (32 * ob + 4 * h) * kExLd + i;    // ... of its 64-wide block (y, dy, yb)
+    const int exA = (32 * w + i) * kExLd + h;          // outer products: A operand of k-step s = image[32 w + i][2 s + h]
+    constexpr int AO1 = 2 * kLD2 * 4, AO3 = 2 * kLD3 * 4, BOX = 2 * kExLd * 4;
+
+    f32x16 acc2h[4], acc2t[4], acc3h[2], acc3t[2];     // dW2 row block w (hjb, termination), dW3 row block w: accumulators of the whole launch
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { zero16(acc2h[j]); zero16(acc2t[j]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { zero16(acc3h[j]); zero16(acc3t[j]); }
+    float w1h[N], w1t[N];                              // dW1[k][f], f = tid & 127, over the samples 16 (tid >> 7) .. + 15 of every tile
+#pragma unroll
+    for (int k = 0; k < N; ++k) w1h[k] = w1t[k] = 0.f;
+    const int fW1 = tid & 127, sW1 = 16 * (tid >> 7);
+    double acc_h = 0, acc_t = 0, acc_ni = 0, acc_nd = 0;
+
+    // outer products of one 32-sample tile (coop_outer below): acc[j] += A (x) B_j over the 16 k-steps (2 samples each)
+    auto fetch = [&](int64_t tile, float (&xv)[N], float& dnv, float& cstv) __attribute__((always_inline)) {
+        const int64_t env = tile * 32 + i;
+        const bool ok = tile < ntiles && env < B;
+        if (ok) load_row<N>(x, env, xv);
+        else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) xv[k] = p.xf[k];
+        }
+        dnv = ok ? done[env] : 0.f;
+        cstv = ok ? cost[env] : 1.f;
+    };
+    float xs_n[N], dn_n, cst_n;
+    fetch(blockIdx.x, xs_n, dn_n, cst_n);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");   // the weights are loop invariant: keep their LDS reads inside the loop (see hjbx_mlp.hip)
+        LP E0 = E0g, E1 = E1g, E2 = E2g, rsp = rsg, zsp = zsg, gzbsp = gzbsg;
+        asm volatile("" : "+v"(E0), "+v"(E1), "+v"(E2), "+v"(rsp), "+v"(zsp), "+v"(gzbsp));   // (see LP above)
+        const bool valid = tile * 32 + i < B;
+        float xs[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) xs[k] = xs_n[k];
+        const float dn = dn_n, cst = cst_n;
+        fetch(tile + gridDim.x, xs_n, dn_n, cst_n);
+        float e[N], z[N], ee = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) e[k] = xs[k] - p.xf[k];
+        sys.wrap(e);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            ee += e[k] * e[k];
+            z[k] = (e[k] - p.mean[k]) * p.istd[k];
+        }
+        float ring1[3][1];
+        f32x16 t[1][1];
+
+        // ---- 1. h1 = act(W1'z): B operands are this lane's own z ------------------------------------------------------------------------
+        zero_acc(t);
+        mfma_chain<OffW1Fc, N / 2, 1, 2, 1>(t, ring1, aW1f, [&](int st, int) { return h ? z[2 * st + 1] : z[2 * st]; });
+        f32x16 h1r;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1r[r] = act1<ACT>(t[0][0][r]);
+        ex_write(E0 + exW, h1r);
+        __syncthreads();                                                                    // (A) E0 = h1
+        // ---- 2. h2 = act(W2'h1) -------------------------------------------------------------------------------------------------------
+        f32x16 acc;
+        zero16(acc);
+        coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));
+        f32x16 h2r;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2r[r] = act1<ACT>(acc[r]);
+        ex_write(E1 + exW, h2r);
+        __syncthreads();                                                                    // (B) E1 = h2
+        // ---- 3. y = W3'h2: block ob, contraction half kh; halves summed through E2; V, r --------------------------------------------------
+        zero16(acc);
+        coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));
+        if (kh == 1) ex_write(E2 + exWy, acc);
+        __syncthreads();                                                                    // (C) E2[0:64] = the upper half's partial y
+        f32x16 dyr;                                                                         // (waves 0, 1: block ob of dy = 2 y)
+        zero16(dyr);
+        if (kh == 0) {
+            ex_add(acc, E2 + exWy);
+            float vpart = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                vpart += acc[r] * acc[r];
+                dyr[r] = acc[r] + acc[r];
+            }
+            vpart += __shfl_xor(vpart, 32, 64);
+            if (h == 0) L.vp[ob][i] = vpart;
+            ex_write(E0 + exWy, dyr);
+        }
+        __syncthreads();                                                                    // (D) E0[0:64] = dy, vp
+        const float V = (L.vp[0][i] + L.vp[1][i]) + p.eps_s * ee;
+        float lt, rterm;
+        termination_residual_env<float>(eps_term, V, cst, dn, lt, rterm);
+        if (!valid) lt = rterm = 0.f;
+        if (w == 0 && h == 0) L.rs[i] = rterm;
+        // ---- 4. d2 = (W3 dy).s2 -------------------------------------------------------------------------------------------------------
+        zero16(acc);
+        coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));
+        f32x16 d2r;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2r[r] = dact1<ACT>(h2r[r], acc[r]);
+        ex_write(E1 + exW, d2r);                                                            // (h2's readers finished before (C))
+        __syncthreads();                                                                    // (E) E1 = d2, rs
+        // ---- 5. d1 = (W2 d2).s1; g = W1 d1 / std + 2 eps_s e; the hjb residual ------------------------------------------------------------
+        zero16(acc);
+        coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E1 + exB));
+        f32x16 d1r;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1r[r] = dact1<ACT>(h1r[r], acc[r]);
+        ex_write(E2 + exW, d1r);                                                            // (the partial y's readers finished before (D))
+        zero_acc(t);
+        mfma_chain<OffW1Gc, 16, 1, 2, 1>(t, ring1, aW1g, [&](int st, int) { return d1r[st]; });
+        {   // partial g of this wave's 32 features: rows k < n of the result, into E0 (dy's readers finished before (E)) as [w][k][sample]
+            LP gp = E0 + w * (N * 32) + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k0 = perm(r);                  // row of lane half 0; lane half 1 holds row k0 + 4
+                if (k0 + 4 * h < N && (k0 < N)) gp[(k0 + 4 * h) * 32] = t[0][0][r];
+            }
+        }
+        __syncthreads();                                                                    // (F) E2 = d1, E0 = partial g
+        float g[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            LPc gp = E0 + k * 32 + i;
+            g[k] = ((gp[0] + gp[N * 32]) + (gp[2 * N * 32] + gp[3 * N * 32])) * p.istd[k] + 2.f * p.eps_s * e[k];
+        }
+        float li, q[N];
+        hjb_residual_env<MODE>(sys, tk, lim, xs, g, dn, true, li, q);
+        if (!valid) {   // padding lanes of the last tile contribute nothing
+            li = 0.f;
+#pragma unroll
+            for (int k = 0; k < N; ++k) q[k] = 0.f;
+        }
+        float gzb[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) gzb[k] = q[k] * p.istd[k];
+        if (w == 0 && h == 0) {
+            if (valid) { acc_h += (double)li; acc_t += (double)lt; acc_ni += 1.0 - (double)dn; acc_nd += (double)dn; }
+#pragma unroll
+            for (int k = 0; k < N; ++k) { L.zs[i * NP + k] = z[k]; L.gzbs[i * NP + k] = gzb[k]; }
+        }
+        // ---- 6. t1 = W1'gzb, dh1b = t1.s1 (B operands: this lane's own gzb) ---------------------------------------------------------------
+        zero_acc(t);
+        mfma_chain<OffW1Fc, N / 2, 1, 2, 1>(t, ring1, aW1f, [&](int st, int) { return h ? gzb[2 * st + 1] : gzb[2 * st]; });
+        f32x16 c1r;                                                                         // tanh: -2 h1 . d1 . t1 (second-order term of a1b)
+        f32x16 dh1b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (ACT == HJBX_ACT_TANH) c1r[r] = -2.f * h1r[r] * d1r[r] * t[0][0][r];
+            dh1b[r] = dact1<ACT>(h1r[r], t[0][0][r]);
+        }
+        __syncthreads();                                                                    // (G) zs, gzbs visible; partial g read
+        // dW1, first part (VALU): gzb (x) d1 and z (x) (r d1), d1 from E2
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        using LP4 = const __attribute__((address_space(3))) f32x4*;
+        LPc d1p = E2 + fW1 * kExLd + sW1, rp1 = rsp + sW1;
+        const LP4 gz4 = (LP4)(gzbsp + sW1 * NP), zz4 = (LP4)(zsp + sW1 * NP);
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float d = d1p[s];
+            const float rd = rp1[s] * d;
+#pragma unroll
+            for (int k4 = 0; k4 < NP / 4; ++k4) {
+                const f32x4 gz = gz4[s * (NP / 4) + k4];
+                const f32x4 zz = zz4[s * (NP / 4) + k4];
+                const float gv[4] = {gz[0], gz[1], gz[2], gz[3]}, zv[4] = {zz[0], zz[1], zz[2], zz[3]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * k4 + c < N) { w1h[4 * k4 + c] += gv[c] * d; w1t[4 * k4 + c] += zv[c] * rd; }
+            }
+        }
+        __syncthreads();                                                                    // (H) d1 read: E2 may be overwritten
+        ex_write(E0 + exW, dh1b);
+        ex_write(E2 + exW, h1r);
+        __syncthreads();                                                                    // (I) E0 = dh1b, E2 = h1, E1 = d2
+        coop_outer<4, true, true>(acc2h, E0, E1, acc2t, E2, E1, rsp, exA, exB, h);              // dW2 += dh1b (x) d2;  dW2_t += h1 (x) (r d2)
+        // ---- 7. t2 = W2'dh1b, dh2b = t2.s2 -------------------------------------------------------------------------------------------------
+        zero16(acc);
+        coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));
+        f32x16 c2r;
+        f32x16 dh2b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (ACT == HJBX_ACT_TANH) c2r[r] = -2.f * h2r[r] * d2r[r] * acc[r];
+            dh2b[r] = dact1<ACT>(h2r[r], acc[r]);
+        }
+        __syncthreads();                                                                    // (J) the outer products above have read E1, E2
+        ex_write(E1 + exW, dh2b);
+        if (kh == 0) ex_write(E2 + exWy, dyr);
+        __syncthreads();                                                                    // (K) E1 = dh2b, E2[0:64] = dy
+        coop_outer<2, true, false>(acc3h, E1, E2, acc3t, E1, E2, rsp, exA, exB, h);    // dW3 += dh2b (x) dy
+        // ---- 8. yb = 2 W3'dh2b (halves summed through E0) ------------------------------------------------------------------------------------
+        zero16(acc);
+        coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));
+        if (kh == 1) ex_write(E0 + exWy, acc);                                              // (dh1b's readers, chain 7, finished before (J))
+        __syncthreads();                                                                    // (L) E0[0:64] = the upper half's partial
+        if (kh == 0) {
+            ex_add(acc, E0 + exWy);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc[r];
+            ex_write(E0 + exWy, acc);                                                       // (each wave rewrites exactly the rows it has just read)
+        }
+        ex_write(E1 + exW, h2r);                                                            // (dh2b's readers, the outer products and chain 8, are past (L))
+        __syncthreads();                                                                    // (M) E0[0:64] = yb, E1 = h2, E2[0:64] = dy
+        coop_outer<2, true, true>(acc3h, E1, E0, acc3t, E1, E2, rsp, exA, exB, h);              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
+        // ---- 9. a2b = (W3 yb).s2 [+ c2] ------------------------------------------------------------------------------------------------------
+        zero16(acc);
+        coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));
+        f32x16 a2b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a2b[r] = dact1<ACT>(h2r[r], acc[r]);
+            if constexpr (ACT == HJBX_ACT_TANH) a2b[r] += c2r[r];
+        }
+        __syncthreads();                                                                    // (N) the outer products above have read E1, E2
+        ex_write(E2 + exW, a2b);
+        ex_write(E1 + exW, h1r);
+        __syncthreads();                                                                    // (O) E2 = a2b, E1 = h1
+        coop_outer<4, true, false>(acc2h, E1, E2, acc2t, E1, E2, rsp, exA, exB, h);    // dW2 += h1 (x) a2b
+        // ---- 10. a1b = (W2 a2b).s1 [+ c1]; dW1 second part ----------------------------------------------------------------------------------
+        zero16(acc);
+        coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E2 + exB));
+        f32x16 a1b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a1b[r] = dact1<ACT>(h1r[r], acc[r]);
+            if constexpr (ACT == HJBX_ACT_TANH) a1b[r] += c1r[r];
+        }
+        ex_write(E0 + exW, a1b);                                                            // (yb's readers, chain 9 and the outer products, finished before (N))
+        __syncthreads();                                                                    // (P) E0 = a1b
+        LPc a1p = E0 + fW1 * kExLd + sW1;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float a = a1p[s];
+#pragma unroll
+            for (int k4 = 0; k4 < NP / 4; ++k4) {
+                const f32x4 zz = zz4[s * (NP / 4) + k4];
+                const float zv[4] = {zz[0], zz[1], zz[2], zz[3]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * k4 + c < N) w1h[4 * k4 + c] += zv[c] * a;
+            }
+        }
+        __syncthreads();                                                                    // (Q) the tile's images and small arrays are free again
+    }
+    // ---- partial sums of this workgroup (added in workgroup order by k_train_coop_reduce: deterministic, no float atomics) ------------------
+    float* out = partial + (int64_t)blockIdx.x * kCoopBlocks * 1024;
+    auto put = [&](int blk, const f32x16& a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[blk * 1024 + r * 64 + lane] = a[r];
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { put(w * 4 + j, acc2h[j]); put(kCoopSet + w * 4 + j, acc2t[j]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { put(16 + w * 2 + j, acc3h[j]); put(kCoopSet + 16 + w * 2 + j, acc3t[j]); }
+    float* o1 = partial_w1 + ((int64_t)blockIdx.x * 2 + (tid >> 7)) * (2 * N * 128);
+#pragma unroll
+    for (int k = 0; k < N; ++k) { o1[k * 128 + fW1] = w1h[k]; o1[(N + k) * 128 + fW1] = w1t[k]; }
+    if (w == 0) {   // loss sums and counts: lanes -> wave (fixed shuffle tree) -> one record
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc_h += __shfl_down(acc_h, off, 64); acc_t += __shfl_down(acc_t, off, 64);
+            acc_ni += __shfl_down(acc_ni, off, 64); acc_nd += __shfl_down(acc_nd, off, 64);
+        }
+        if (lane == 0) {
+            double* rec = sums_rec + 4 * (int64_t)blockIdx.x;
+            rec[0] = acc_h; rec[1] = acc_t; rec[2] = acc_ni; rec[3] = acc_nd;
+        }
+    }
+}
+
+// ---- partial sums -> flat gradient buffer, in workgroup order ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts,
+                                                          const double* __restrict__ sums_rec, float* __restrict__ flat) {
+    constexpr int P = N * kH1 + kH1 * kH2 + kH2 * kH3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < kCoopBlocks * 1024) {
+        // fixed order: four interleaved running sums over the workgroups (four loads in flight), then ((s0 + s1) + (s2 + s3))
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        int gI = 0;
+        for (; gI + 4 <= nparts; gI += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += partial[(int64_t)(gI + k) * kCoopBlocks * 1024 + t];
+        }
+        for (int k = 0; gI < nparts; ++gI, ++k) s4[k] += partial[(int64_t)gI * kCoopBlocks * 1024 + t];
+        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        const int blk = t >> 10, reg = (t >> 6) & 15, lane = t & 63;
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+        const int set = blk / kCoopSet, b = blk % kCoopSet;
+        float* o = flat + set * P;
+        if (b < 16) o[N * kH1 + (32 * (b >> 2) + row) * kH2 + 32 * (b & 3) + col] = s;
+        else o[N * kH1 + kH1 * kH2 + (32 * ((b - 16) >> 1) + row) * kH3 + 32 * ((b - 16) & 1) + col] = s;
+    } else if (t < kCoopBlocks * 1024 + 2 * N * 128) {
+        const int u = t - kCoopBlocks * 1024;          // (set, k, f)
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        const int np2 = 2 * nparts;                    // two sample halves per workgroup
+        int gI = 0;
+        for (; gI + 4 <= np2; gI += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += partial_w1[(int64_t)(gI + k) * (2 * N * 128) + u];
+        }
+        for (int k = 0; gI < np2; ++gI, ++k) s4[k] += partial_w1[(int64_t)gI * (2 * N * 128) + u];
+        const int set = u / (N * 128), kf = u % (N * 128);
+        flat[set * P + kf] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    } else if (t < kCoopBlocks * 1024 + 2 * N * 128 + 4) {
+        const int k = t - (kCoopBlocks * 1024 + 2 * N * 128);
+        double s = 0;
+        for (int g = 0; g < nparts; ++g) s += sums_rec[4 * g + k];
+        flat[2 * P + k] = (float)s;
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------
+struct CoopWs { size_t partial, partial_w1, sums, total; int grid; };
+static CoopWs coop_ws(int64_t B, int n) {
+    CoopWs w{};
+    int n_cu = hjbx_device_cus();
+    if (n_cu <= 0) n_cu = 256;
+    const int64_t ntiles = (B + 31) / 32;
+    w.grid = (int)(ntiles < n_cu ? ntiles : n_cu);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    w.partial = up((size_t)w.grid * kCoopBlocks * 1024 * sizeof(float));
+    w.partial_w1 = up((size_t)w.grid * 2 * 2 * n * 128 * sizeof(float));
+    w.sums = up((size_t)w.grid * 4 * sizeof(double));
+    w.total = w.partial + w.partial_w1 + w.sums;
+    return w;
+}
+
+size_t hjbx_train_coop_workspace_bytes(int64_t B, int n) { return B > 0 ? coop_ws(B, n).total : 0; }
+
+template <typename S>
+static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
+                       const float* done, float* flat, void* workspace, int64_t B, void* st) {
+    constexpr int N = S::N, M = S::M;
+    if constexpr (N % 2 != 0 || N > HJBX_MAX_N) {
+        return HJBX_EUNSUPPORTED;
+    } else {
+        if (hjbx_device_cus() <= 0) return hjbx_set_error(HJBX_ENODEVICE, "hjbx_value_loss_grad_f32: no HIP device");
+        MlpP<N> p;
+        for (int k = 0; k < N; ++k) { p.mean[k] = (float)mlp->mean[k]; p.istd[k] = (float)(1.0 / mlp->std[k]); p.xf[k] = (float)mlp->xf[k]; }
+        p.eps_s = (float)mlp->eps_scalar;
+        const auto tk = make_task<float, N, M>(task);
+        const auto lim = make_limits<float, M>(sysh);
+        const CoopWs w = coop_ws(B, N);
+        float* partial = (float*)workspace;
+        float* partial_w1 = (float*)((char*)workspace + w.partial);
+        double* sums = (double*)((char*)workspace + w.partial + w.partial_w1);
+        const int64_t ntiles = (B + 31) / 32;
+        const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
+        hipStream_t s = (hipStream_t)st;
+        auto go = [&](auto mode_c, auto act_c) {
+            hipLaunchKernelGGL((k_train_coop<decltype(mode_c)::value, decltype(act_c)::value, S>), dim3(w.grid), dim3(256), 0, s, sys, p, tk, lim, W1, W2, W3, x,
+                               cost, done, (float)task->eps, partial, partial_w1, sums, B, ntiles);
+        };
+        const bool tanh_net = mlp->activation == HJBX_ACT_TANH;
+        if (mode == HJBX_RESIDUAL_NORMALISED) {
+            if (tanh_net) go(std::integral_constant<int, 0>{}, std::integral_constant<int, HJBX_ACT_TANH>{});
+            else go(std::integral_constant<int, 0>{}, std::integral_constant<int, HJBX_ACT_RELU>{});
+        } else {
+            if (tanh_net) go(std::integral_constant<int, 1>{}, std::integral_constant<int, HJBX_ACT_TANH>{});
+            else go(std::integral_constant<int, 1>{}, std::integral_constant<int, HJBX_ACT_RELU>{});
+        }
+        const int nthreads = kCoopBlocks * 1024 + 2 * N * 128 + 4;
+        hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, flat);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: %s", hipGetErrorString(e));
+        return HJBX_OK;
+    }
+}
+
+// called by hjbx_value_loss_grad_f32 (hjbx_train.hip) after it has validated its arguments
+int hjbx_train_coop(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost, const float* done,
+                    float* flat, void* workspace, int64_t B, void* stream) {
+    int rc = HJBX_EUNSUPPORTED;
+#ifdef HJBX_TRAIN_DEV   // development builds: cartpole only
+    bool ok = false;
+    if (sys->kind == HJBX_SYS_CARTPOLE) {
+        Cartpole<float> cp{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
+        rc = launch_coop<Cartpole<float>>(sys, cp, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+        ok = true;
+    }
+#else
+    const bool ok = with_system<float>(sys, [&](auto S) { rc = launch_coop<decltype(S)>(sys, S, task, mlp, mode, x, cost, done, flat, workspace, B, stream); });
+#endif
+    if (!ok || rc == HJBX_EUNSUPPORTED)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
+    return rc;
+}

@@ -16,6 +16,18 @@ from test_gpu_vhjb import _autograd_losses, controller, states_near_target
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["coop/f32", "pair/f32", "pair/f16x2"])
+def impl(request):
+    """The implementations of hjbx_value_loss_grad_f32: the cooperative single kernel (float32 MFMA; the default), the round-2 pair of kernels
+    in float32 (HJBX_OPT_TRAIN_KERNEL = 1) and the same pair with f16x2 split-operand chains (HJBX_OPT_MLP_ARITHMETIC = 2)."""
+    kernel, arithmetic = request.param.split("/")
+    pa = _abi.set_option(_abi.OPT_MLP_ARITHMETIC, {"f32": 0, "f16x2": 2}[arithmetic])
+    pk = _abi.set_option(_abi.OPT_TRAIN_KERNEL, 1 if kernel == "pair" else 0)
+    yield request.param
+    _abi.set_option(_abi.OPT_MLP_ARITHMETIC, pa)
+    _abi.set_option(_abi.OPT_TRAIN_KERNEL, pk)
+
+
 def _batch(d, ctl, B, seed, frac=0.6, p_done=0.3):
     xs = states_near_target(d, ctl, B, seed, frac)
     rng = np.random.default_rng(seed + 100)
@@ -26,7 +38,7 @@ def _batch(d, ctl, B, seed, frac=0.6, p_done=0.3):
 
 def _reference_sums_f64(name, ctl32, xs, dones, costs, mode=_abi.RESIDUAL_NORMALISED):
     """float64 autograd double back-prop of the loss SUMS on the float32 weights -> (g_h list, g_t list, scalars)"""
-    d64, ctl64 = controller(name, torch.float64, residual_mode=mode)
+    d64, ctl64 = controller(name, torch.float64, residual_mode=mode, activation=ctl32.value_function_approximator.activation)
     with torch.no_grad():
         for w64, w32 in zip(ctl64.value_function_approximator.weights, ctl32.value_function_approximator.weights):
             w64.copy_(w32.double())
@@ -59,7 +71,7 @@ def _unpack(flat, n):
 
 @pytest.mark.parametrize("B", [1, 33, 256, 1000])
 @pytest.mark.parametrize("name", SYSTEMS)
-def test_value_loss_grad_vs_f64_autograd(name, B, arith):
+def test_value_loss_grad_vs_f64_autograd(name, B, impl):
     """float32 MFMA kernels vs float64 autograd double back-prop: every gradient matrix to 1e-4 of its largest entry (per element) and
     1e-4 in the Frobenius norm; loss sums to 1e-5; counts exact.  B = 1 / 33 / 1000 exercise padding lanes and partial tiles."""
     d, ctl = controller(name)
@@ -87,7 +99,7 @@ def test_value_loss_grad_vs_f64_autograd(name, B, arith):
 
 
 @pytest.mark.parametrize("name", ["cartpole", "quad2d"])
-def test_value_loss_grad_raw_residual_mode(name, arith):
+def test_value_loss_grad_raw_residual_mode(name, impl):
     """HJBX_RESIDUAL_RAW (|gradV.xdot + l|, examples/cartpole_balancing.ipynb cell 11) against autograd through the f64 HIP residual op."""
     d, ctl = controller(name, residual_mode=_abi.RESIDUAL_RAW)
     vf = ctl.value_function_approximator
@@ -101,7 +113,7 @@ def test_value_loss_grad_raw_residual_mode(name, arith):
         assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-30)
 
 
-def test_value_loss_grad_properties_at_scale(arith):
+def test_value_loss_grad_properties_at_scale(impl):
     """B = 2^17 + 77 (more tiles than workgroups, ragged tail): (a) bitwise reproducible, (b) additive over a split of the batch,
     (c) samples marked done contribute nothing to the hjb set and only they contribute to the termination set."""
     d, ctl = controller("cartpole")
@@ -150,14 +162,73 @@ def test_fused_and_autograd_updates_agree():
         assert float((da - db)[big].abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("mode", [_abi.RESIDUAL_NORMALISED, _abi.RESIDUAL_RAW])
+@pytest.mark.parametrize("B", [33, 256, 1000])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_value_loss_grad_tanh_network_vs_f64_autograd(name, B, mode):
+    """The tanh network of examples/cartpole_balancing.ipynb cell 6 in the fused kernel: act'' != 0 adds the second-order terms
+    -2 h . d . t to the reverse sweep (derivation at the top of csrc/hjbx_train_coop.hip).  Against float64 torch.autograd double back-prop of
+    the plain loss formulas with torch.tanh, same bounds as the ReLU network: 1e-4 of each matrix's largest entry and 1e-4 in Frobenius norm.
+    Both residual modes (the notebook trains with the RAW residual, cell 11)."""
+    d, ctl = controller(name, activation="tanh", residual_mode=mode)
+    assert ctl.fused_param_grad
+    vf = ctl.value_function_approximator
+    with torch.no_grad():
+        for w in vf.weights:
+            w.mul_(1.5)                                        # part of the units towards saturation: h^2 and the -2 h d t terms matter
+    xs, dones, costs = _batch(d, ctl, B, 41)
+    flat = _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs, costs, dones, mode=mode)
+    gh, gt, sc = _unpack(flat, d.state_dim)
+    rh, rt, rsc = _reference_sums_f64(name, ctl, xs, dones, costs, mode=mode)
+    assert sc[2] == rsc[2] and sc[3] == rsc[3]
+    assert abs(sc[0] - rsc[0]) <= 2e-5 * abs(rsc[0]) + 1e-6 and abs(sc[1] - rsc[1]) <= 2e-5 * abs(rsc[1]) + 1e-6, (sc, rsc)
+    for label, got, want in (("hjb", gh, rh), ("termination", gt, rt)):
+        for k, (a, b) in enumerate(zip(got, want)):
+            b = b.cpu().numpy()
+            scale = np.abs(b).max()
+            if scale == 0:
+                assert np.abs(a).max() == 0
+                continue
+            err = np.abs(a - b)
+            assert err.max() <= 1e-4 * scale, f"tanh {label} dW{k + 1}: max err {err.max():.3e} vs scale {scale:.3e} (rel {err.max() / scale:.2e})"
+            assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), f"tanh {label} dW{k + 1}: Frobenius rel {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
+    # the second-order terms are really there: dropping them (= treating tanh like a piecewise-linear unit) would be far outside the bound
+    if B == 256 and mode == _abi.RESIDUAL_NORMALISED:
+        assert np.abs(rh[1].cpu().numpy()).max() > 0
+
+
+def test_tanh_updates_through_the_fused_kernels_match_autograd():
+    """params_update of a tanh controller (the notebook recipe that reproduces the reference's cartpole anchor) through the fused kernels ==
+    through PyTorch autograd: losses to 1e-5, gradients to 1e-4 of each matrix's largest entry."""
+    res = {}
+    for fused in (True, False):
+        d, ctl = controller("cartpole", activation="tanh", fused_param_grad=fused, graph_updates=False, residual_mode=_abi.RESIDUAL_RAW)
+        assert ctl.fused_param_grad == fused
+        xs, dones, costs = _batch(d, ctl, 256, 3)
+        tot, h, t = ctl.params_update(xs, dones, costs, 0.37)
+        res[fused] = (float(tot), float(h), float(t), [p.grad.detach().clone() for p in ctl.value_function_approximator.parameters()])
+    a, b = res[True], res[False]
+    for k in range(3):
+        assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-7
+    for ga, gb in zip(a[3], b[3]):
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+
+
 def test_value_loss_grad_rejects_what_it_cannot_do():
-    d, ctl = controller("cartpole", activation="tanh")
+    d, ctl = controller("cartpole", activation="sin")
     xs, dones, costs = _batch(d, ctl, 64, 1)
     with pytest.raises(NotImplementedError):
         _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs, costs, dones)
-    assert not ctl.fused_param_grad                              # the controller falls back to autograd for tanh on its own
+    assert not ctl.fused_param_grad                              # the controller falls back to autograd for sin on its own
     with pytest.raises(NotImplementedError):
-        controller("cartpole", activation="tanh", fused_param_grad=True)
+        controller("cartpole", activation="sin", fused_param_grad=True)
+    d, ctl = controller("cartpole", activation="tanh")
+    prev = _abi.set_option(_abi.OPT_TRAIN_KERNEL, 1)             # tanh exists in the cooperative kernel only: the option does not apply to it
+    try:
+        flat = _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs, costs, dones)
+        assert torch.isfinite(flat).all()
+    finally:
+        _abi.set_option(_abi.OPT_TRAIN_KERNEL, prev)
     d, ctl = controller("cartpole")
     flat = _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs[:0].contiguous(), costs[:0].contiguous(),
                                 dones[:0].contiguous())

@@ -314,7 +314,8 @@ def _autograd_losses(ctl, xs, dones, costs):
     x = xs.clone().requires_grad_(True)
     e = x - vf.xf                                              # test states are away from the seam
     z = (e - vf.mean) / vf.std
-    y = torch.relu(torch.relu(z @ vf.weights[0]) @ vf.weights[1]) @ vf.weights[2]
+    act = vf._ACT[vf.activation][0]                            # relu (controller/vhjb.py), tanh / sin (the notebooks' networks)
+    y = act(act(z @ vf.weights[0]) @ vf.weights[1]) @ vf.weights[2]
     V = (y * y).sum(-1) + vf.epsilon_scalar * (e * e).sum(-1)
     g, = torch.autograd.grad(V.sum(), x, create_graph=True)
     f1, f2 = _ops.affine(d.system, xs)
