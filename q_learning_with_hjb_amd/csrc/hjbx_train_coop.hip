@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     const int exW = (32 * w + 4 * h) * kExLd + i;      // this lane's writes of its wave's 128-wide block
     const int exWy = (32 * ob + 4 * h) * kExLd + i;    // ... of its 64-wide block (y, dy, yb)
     const int exA = (32 * w + i) * kExLd + h;          // outer products: A operand of k-step s = image[32 w + i][2 s + h]
+    const int exO = i * kExLd + h;                     //                 B operand of column block j = image[32 j + i][2 s + h]
     constexpr int AO1 = 2 * kLD2 * 4, AO3 = 2 * kLD3 * 4, BOX = 2 * kExLd * 4;
 
     f32x16 acc2h[4], acc2t[4], acc3h[2], acc3t[2];     // dW2 row block w (hjb, termination), dW3 row block w: accumulators of the whole launch
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         ex_write(E0 + exW, dh1b);
         ex_write(E2 + exW, h1r);
         __syncthreads();                                                                    // (I) E0 = dh1b, E2 = h1, E1 = d2
-        coop_outer<4, true, true>(acc2h, E0, E1, acc2t, E2, E1, rsp, exA, exB, h);              // dW2 += dh1b (x) d2;  dW2_t += h1 (x) (r d2)
+        coop_outer<4, true, true>(acc2h, E0, E1, acc2t, E2, E1, rsp, exA, exO, h);              // dW2 += dh1b (x) d2;  dW2_t += h1 (x) (r d2)
         // ---- 7. t2 = W2'dh1b, dh2b = t2.s2 -------------------------------------------------------------------------------------------------
         zero16(acc);
         coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         ex_write(E1 + exW, dh2b);
         if (kh == 0) ex_write(E2 + exWy, dyr);
         __syncthreads();                                                                    // (K) E1 = dh2b, E2[0:64] = dy
-        coop_outer<2, true, false>(acc3h, E1, E2, acc3t, E1, E2, rsp, exA, exB, h);    // dW3 += dh2b (x) dy
+        coop_outer<2, true, false>(acc3h, E1, E2, acc3t, E1, E2, rsp, exA, exO, h);    // dW3 += dh2b (x) dy
         // ---- 8. yb = 2 W3'dh2b (halves summed through E0) ------------------------------------------------------------------------------------
         zero16(acc);
         coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         }
         ex_write(E1 + exW, h2r);                                                            // (dh2b's readers, the outer products and chain 8, are past (L))
         __syncthreads();                                                                    // (M) E0[0:64] = yb, E1 = h2, E2[0:64] = dy
-        coop_outer<2, true, true>(acc3h, E1, E0, acc3t, E1, E2, rsp, exA, exB, h);              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
+        coop_outer<2, true, true>(acc3h, E1, E0, acc3t, E1, E2, rsp, exA, exO, h);              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
         // ---- 9. a2b = (W3 yb).s2 [+ c2] ------------------------------------------------------------------------------------------------------
         zero16(acc);
         coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         ex_write(E2 + exW, a2b);
         ex_write(E1 + exW, h1r);
         __syncthreads();                                                                    // (O) E2 = a2b, E1 = h1
-        coop_outer<4, true, false>(acc2h, E1, E2, acc2t, E1, E2, rsp, exA, exB, h);    // dW2 += h1 (x) a2b
+        coop_outer<4, true, false>(acc2h, E1, E2, acc2t, E1, E2, rsp, exA, exO, h);    // dW2 += h1 (x) a2b
         // ---- 10. a1b = (W2 a2b).s1 [+ c1]; dW1 second part ----------------------------------------------------------------------------------
         zero16(acc);
         coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E2 + exB));
