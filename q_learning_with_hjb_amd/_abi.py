@@ -30,7 +30,7 @@ OPT_ROLLOUT_SCHEDULE, OPT_ROLLOUT_EXTRA_WORKGROUPS, OPT_STREAM_ROWS, OPT_MLP_ARI
 OK, EINVAL, EUNSUPPORTED, EHIP, ENODEVICE = 0, -1, -2, -3, -4
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_LIB_PATH = os.path.join(_CSRC, "libhjbx.so")
+_LIB_PATH = os.environ.get("HJBX_LIBRARY") or os.path.join(_CSRC, "libhjbx.so")   # (HJBX_LIBRARY: development builds of tools/dev)
 # (source, extra flags, object): hjbx_mlp.hip is compiled once per activation (see the top of that file)
 _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=0",), "hjbx_mlp_relu.o"),

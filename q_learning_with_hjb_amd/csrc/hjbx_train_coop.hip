@@ -53,6 +53,8 @@ template <int N> struct CoopLds {
     float rs[32];                                      // r = d loss_term / d V per sample
     float vp[2][32];                                   // |y|^2 partial sums of the two 32-row blocks of y
     float zeros[32];                                   // A operand of the lanes that stand for rows >= n of W1 (g product)
+    double sums[4][32];                                // running loss sums / counts per sample slot (wave 0 adds to them once per tile: 8 registers less
+                                                       // through the whole tile loop than four double accumulators per lane)
 };
 
 // ---- a chain whose A (weights) AND B (an exchange image) operands both come from LDS ------------------------------------------------
@@ -63,8 +65,12 @@ template <int AOFF, int BOFF, int ST> __device__ __forceinline__ void coop_issue
     a = lds_read_b32<AOFF * ST>(abase);
     b = lds_read_b32<BOFF * ST>(bbase);
 }
-template <int AOFF, int BOFF, int NSTEPS, int DEPTH, int ST>
-__device__ __forceinline__ void coop_chain_step(f32x16& acc, float (&ra)[DEPTH + 1], float (&rb)[DEPTH + 1], uint32_t abase, uint32_t bbase) {
+// `filler(integral_constant<int, st>)` runs after the MFMA of step st: independent VALU / LDS work placed there issues while the matrix pipe
+// executes that MFMA (64 cycles), i.e. for free -- with ONE wave per SIMD nothing else can hide it.  (LDS reads the compiler adds between
+// the asm reads only make the counted waits conservative: LDS returns in order.)
+struct NoFiller { template <typename I> __device__ __forceinline__ void operator()(I) const {} };
+template <int AOFF, int BOFF, int NSTEPS, int DEPTH, int ST, typename Filler>
+__device__ __forceinline__ void coop_chain_step(f32x16& acc, float (&ra)[DEPTH + 1], float (&rb)[DEPTH + 1], uint32_t abase, uint32_t bbase, const Filler& filler) {
     if constexpr (ST < NSTEPS) {
         if constexpr (ST + DEPTH < NSTEPS) coop_issue<AOFF, BOFF, ST + DEPTH>(ra[(ST + DEPTH) % (DEPTH + 1)], rb[(ST + DEPTH) % (DEPTH + 1)], abase, bbase);
         __builtin_amdgcn_sched_barrier(0);
@@ -72,17 +78,19 @@ __device__ __forceinline__ void coop_chain_step(f32x16& acc, float (&ra)[DEPTH +
         lds_wait<ahead>();
         acc = MFMA(ra[ST % (DEPTH + 1)], rb[ST % (DEPTH + 1)], acc);
         __builtin_amdgcn_sched_barrier(0);
-        coop_chain_step<AOFF, BOFF, NSTEPS, DEPTH, ST + 1>(acc, ra, rb, abase, bbase);
+        filler(std::integral_constant<int, ST>{});
+        coop_chain_step<AOFF, BOFF, NSTEPS, DEPTH, ST + 1>(acc, ra, rb, abase, bbase, filler);
     }
 }
-template <int AOFF, int BOFF, int NSTEPS> __device__ __forceinline__ void coop_chain(f32x16& acc, uint32_t abase, uint32_t bbase) {
+template <int AOFF, int BOFF, int NSTEPS, typename Filler = NoFiller>
+__device__ __forceinline__ void coop_chain(f32x16& acc, uint32_t abase, uint32_t bbase, const Filler& filler = Filler()) {
     constexpr int DEPTH = 3;
     static_assert(AOFF * (NSTEPS - 1) < 65536 && BOFF * (NSTEPS - 1) < 65536, "ds_read_b32 offset field is 16 bits");
     float ra[DEPTH + 1], rb[DEPTH + 1];
     coop_issue<AOFF, BOFF, 0>(ra[0], rb[0], abase, bbase);
     if constexpr (NSTEPS > 1) coop_issue<AOFF, BOFF, 1>(ra[1], rb[1], abase, bbase);
     if constexpr (NSTEPS > 2) coop_issue<AOFF, BOFF, 2>(ra[2], rb[2], abase, bbase);
-    coop_chain_step<AOFF, BOFF, NSTEPS, DEPTH, 0>(acc, ra, rb, abase, bbase);
+    coop_chain_step<AOFF, BOFF, NSTEPS, DEPTH, 0>(acc, ra, rb, abase, bbase, filler);
 }
 
 // A operands of the two products whose B operands are registers (mfma_chain of hjbx_mlp_core.hpp, one output block)
@@ -114,21 +122,59 @@ __device__ __forceinline__ void ex_add(f32x16& v, LPc blk) {
 
 // Outer products of one 32-sample tile: acch[j] += A_h (x) B_h,j and acct[j] += A_t (x) (r B_t,j) over the 16 k-steps (2 samples each).
 // A = rows 32 w + i of an image (exA = (32 w + i) kExLd + h), B_j = rows 32 j + i of another (exBj = i kExLd + h), rs = r per sample.
-template <int NB, bool HJB, bool TERM>
-__device__ __forceinline__ void coop_outer(f32x16 (&acch)[NB], LPc Ah, LPc Bh, f32x16 (&acct)[NB], LPc At, LPc Bt, LPc rs, int exA, int exBj, int h) {
+template <int NB, bool HJB, bool TERM, typename Filler = NoFiller>
+__device__ __forceinline__ void coop_outer(f32x16 (&acch)[NB], LPc Ah, LPc Bh, f32x16 (&acct)[NB], LPc At, LPc Bt, LPc rs, int exA, int exBj, int h,
+                                           const Filler& filler = Filler()) {
     LPc ah_p = Ah + exA, bh_p = Bh + exBj, at_p = At + exA, bt_p = Bt + exBj, r_p = rs + h;   // lane bases; everything below is base + constant
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        float ah = 0.f, at = 0.f, rr = 0.f;
-        if constexpr (HJB) ah = ah_p[2 * s];
-        if constexpr (TERM) { at = at_p[2 * s]; rr = r_p[2 * s]; }
+    // software pipeline, pinned by sched_barrier: the operands of k-step s + 1 are read while the MFMAs of k-step s issue; left to itself the
+    // scheduler reads many k-steps ahead and the registers of those loads push long-lived values into scratch
+    struct Ops { float ah, at, rr, bh[NB], bt[NB]; };
+    auto load = [&](int s2) __attribute__((always_inline)) {
+        Ops o;
+        o.ah = o.at = o.rr = 0.f;
+        if constexpr (HJB) o.ah = ah_p[2 * s2];
+        if constexpr (TERM) { o.at = at_p[2 * s2]; o.rr = r_p[2 * s2]; }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            if constexpr (HJB) acch[j] = MFMA(ah, bh_p[32 * j * kExLd + 2 * s], acch[j]);
-            if constexpr (TERM) acct[j] = MFMA(at, rr * bt_p[32 * j * kExLd + 2 * s], acct[j]);
+            o.bh[j] = o.bt[j] = 0.f;
+            if constexpr (HJB) o.bh[j] = bh_p[32 * j * kExLd + 2 * s2];
+            if constexpr (TERM) o.bt[j] = bt_p[32 * j * kExLd + 2 * s2];
         }
+        return o;
+    };
+    Ops cur = load(0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        Ops nxt = cur;
+        if (s + 1 < 16) nxt = load(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (HJB) acch[j] = MFMA(cur.ah, cur.bh[j], acch[j]);
+            if constexpr (TERM) acct[j] = MFMA(cur.at, cur.rr * cur.bt[j], acct[j]);
+        }
+        filler(s);                               // (independent VALU work in the shadow of this k-step's MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
 }
+
+// DEVELOPMENT timing switches (tools/dev/coop_variants.sh builds variants with them; results are garbage, only the time means something)
+#ifdef HJBX_COOP_NO_OUTER
+#define COOP_OUTER(...)
+#else
+#define COOP_OUTER(...) __VA_ARGS__
+#endif
+#ifdef HJBX_COOP_NO_CHAINS
+#define COOP_CHAIN(...)
+#else
+#define COOP_CHAIN(...) __VA_ARGS__
+#endif
+#ifdef HJBX_COOP_NO_BARRIER
+#define COOP_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define COOP_SYNC() __syncthreads()
+#endif
 
 template <int MODE, int ACT, typename S>
 __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k, Limits<float, S::M> lim_k,
@@ -151,6 +197,8 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     for (int idx = tid; idx < kH1 * kH2; idx += 256) L.W2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
     for (int idx = tid; idx < kH2 * kH3; idx += 256) L.W3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
     if (tid < 32) L.zeros[tid] = 0.f;
+    if (tid < 128) L.sums[tid >> 5][tid & 31] = 0.0;
+    for (int idx = tid; idx < kExFloats; idx += 256) L.E[2][idx] = 0.f;   // (the first tile's chain 2 reads "the previous tile's a1b" from here)
     for (int idx = tid; idx < 32 * NP; idx += 256) { L.zs[idx] = 0.f; L.gzbs[idx] = 0.f; }
     __syncthreads();
     const S& sys = sys_s;
@@ -183,11 +231,10 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     for (int j = 0; j < 4; ++j) { zero16(acc2h[j]); zero16(acc2t[j]); }
 #pragma unroll
     for (int j = 0; j < 2; ++j) { zero16(acc3h[j]); zero16(acc3t[j]); }
-    float w1h[N], w1t[N];                              // dW1[k][f], f = tid & 127, over the samples 16 (tid >> 7) .. + 15 of every tile
-#pragma unroll
-    for (int k = 0; k < N; ++k) w1h[k] = w1t[k] = 0.f;
+    f32x2 w1h[N / 2], w1t[N / 2];                      // dW1[k][f], f = tid & 127, over the samples 16 (tid >> 7) .. + 15 of every tile
+#pragma unroll                                         // (pairs of k: one v_pk_fma_f32 per two entries; N is even)
+    for (int k = 0; k < N / 2; ++k) w1h[k] = w1t[k] = f32x2{0.f, 0.f};
     const int fW1 = tid & 127, sW1 = 16 * (tid >> 7);
-    double acc_h = 0, acc_t = 0, acc_ni = 0, acc_nd = 0;
 
     // outer products of one 32-sample tile (coop_outer below): acc[j] += A (x) B_j over the 16 k-steps (2 samples each)
     auto fetch = [&](int64_t tile, float (&xv)[N], float& dnv, float& cstv) __attribute__((always_inline)) {
@@ -212,7 +259,6 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int k = 0; k < N; ++k) xs[k] = xs_n[k];
         const float dn = dn_n, cst = cst_n;
-        fetch(tile + gridDim.x, xs_n, dn_n, cst_n);
         float e[N], z[N], ee = 0.f;
 #pragma unroll
         for (int k = 0; k < N; ++k) e[k] = xs[k] - p.xf[k];
@@ -232,21 +278,49 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1r[r] = act1<ACT>(t[0][0][r]);
         ex_write(E0 + exW, h1r);
-        __syncthreads();                                                                    // (A) E0 = h1
+        COOP_SYNC();                                                                    // (A) E0 = h1
         // ---- 2. h2 = act(W2'h1) -------------------------------------------------------------------------------------------------------
         f32x16 acc;
         zero16(acc);
-        coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));
+        {   // in the shadow of this chain's MFMAs: the PREVIOUS tile's z (x) a1b (a1b in E2, its z still in zs; both zero before the first tile)
+            using f32x4 = __attribute__((ext_vector_type(4))) float;
+            using LP4 = const __attribute__((address_space(3))) f32x4*;
+            LPc a1p = E2 + fW1 * kExLd + sW1;
+            const LP4 zz4 = (LP4)(zsp + sW1 * NP);
+            auto w1_part2 = [&](auto st_c) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_c)::value;
+#if !defined(HJBX_COOP_NO_W1) && !defined(HJBX_COOP_NO_FILL2)
+                if constexpr (st % 4 == 0) {
+                    constexpr int s2 = st / 4;
+                    const float a = a1p[s2];
+                    const f32x2 a2v{a, a};
+#pragma unroll
+                    for (int k4 = 0; k4 < NP / 4; ++k4) {
+                        const f32x4 zz = zz4[s2 * (NP / 4) + k4];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (4 * k4 + 2 * c < N) w1h[2 * k4 + c] = __builtin_elementwise_fma(f32x2{zz[2 * c], zz[2 * c + 1]}, a2v, w1h[2 * k4 + c]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < N / 2; ++k) asm volatile("" : "+v"(w1h[k]));   // (pinned: see w1_part1)
+                }
+#endif
+            };
+#ifdef HJBX_COOP_NO_CHAINS
+            (void)w1_part2;
+#endif
+            COOP_CHAIN(coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB), w1_part2);)
+        }
         f32x16 h2r;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2r[r] = act1<ACT>(acc[r]);
         ex_write(E1 + exW, h2r);
-        __syncthreads();                                                                    // (B) E1 = h2
+        COOP_SYNC();                                                                    // (B) E1 = h2
         // ---- 3. y = W3'h2: block ob, contraction half kh; halves summed through E2; V, r --------------------------------------------------
         zero16(acc);
-        coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));
+        COOP_CHAIN(coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));)
         if (kh == 1) ex_write(E2 + exWy, acc);
-        __syncthreads();                                                                    // (C) E2[0:64] = the upper half's partial y
+        COOP_SYNC();                                                                    // (C) E2[0:64] = the upper half's partial y
         f32x16 dyr;                                                                         // (waves 0, 1: block ob of dy = 2 y)
         zero16(dyr);
         if (kh == 0) {
@@ -261,23 +335,26 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
             if (h == 0) L.vp[ob][i] = vpart;
             ex_write(E0 + exWy, dyr);
         }
-        __syncthreads();                                                                    // (D) E0[0:64] = dy, vp
+        COOP_SYNC();                                                                    // (D) E0[0:64] = dy, vp
         const float V = (L.vp[0][i] + L.vp[1][i]) + p.eps_s * ee;
         float lt, rterm;
         termination_residual_env<float>(eps_term, V, cst, dn, lt, rterm);
         if (!valid) lt = rterm = 0.f;
-        if (w == 0 && h == 0) L.rs[i] = rterm;
+        if (w == 0 && h == 0) {
+            L.rs[i] = rterm;
+            if (valid) { L.sums[1][i] += (double)lt; L.sums[2][i] += 1.0 - (double)dn; L.sums[3][i] += (double)dn; }
+        }
         // ---- 4. d2 = (W3 dy).s2 -------------------------------------------------------------------------------------------------------
         zero16(acc);
-        coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));
+        COOP_CHAIN(coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));)
         f32x16 d2r;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2r[r] = dact1<ACT>(h2r[r], acc[r]);
         ex_write(E1 + exW, d2r);                                                            // (h2's readers finished before (C))
-        __syncthreads();                                                                    // (E) E1 = d2, rs
+        COOP_SYNC();                                                                    // (E) E1 = d2, rs
         // ---- 5. d1 = (W2 d2).s1; g = W1 d1 / std + 2 eps_s e; the hjb residual ------------------------------------------------------------
         zero16(acc);
-        coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E1 + exB));
+        COOP_CHAIN(coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E1 + exB));)
         f32x16 d1r;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1r[r] = dact1<ACT>(h1r[r], acc[r]);
@@ -292,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
                 if (k0 + 4 * h < N && (k0 < N)) gp[(k0 + 4 * h) * 32] = t[0][0][r];
             }
         }
-        __syncthreads();                                                                    // (F) E2 = d1, E0 = partial g
+        COOP_SYNC();                                                                    // (F) E2 = d1, E0 = partial g
         float g[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) {
@@ -300,7 +377,13 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
             g[k] = ((gp[0] + gp[N * 32]) + (gp[2 * N * 32] + gp[3 * N * 32])) * p.istd[k] + 2.f * p.eps_s * e[k];
         }
         float li, q[N];
+#ifdef HJBX_COOP_NO_RESID
+        li = g[0];
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = g[k];
+#else
         hjb_residual_env<MODE>(sys, tk, lim, xs, g, dn, true, li, q);
+#endif
         if (!valid) {   // padding lanes of the last tile contribute nothing
             li = 0.f;
 #pragma unroll
@@ -310,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int k = 0; k < N; ++k) gzb[k] = q[k] * p.istd[k];
         if (w == 0 && h == 0) {
-            if (valid) { acc_h += (double)li; acc_t += (double)lt; acc_ni += 1.0 - (double)dn; acc_nd += (double)dn; }
+            if (valid) L.sums[0][i] += (double)li;
 #pragma unroll
             for (int k = 0; k < N; ++k) { L.zs[i * NP + k] = z[k]; L.gzbs[i * NP + k] = gzb[k]; }
         }
@@ -324,34 +407,44 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
             if constexpr (ACT == HJBX_ACT_TANH) c1r[r] = -2.f * h1r[r] * d1r[r] * t[0][0][r];
             dh1b[r] = dact1<ACT>(h1r[r], t[0][0][r]);
         }
-        __syncthreads();                                                                    // (G) zs, gzbs visible; partial g read
-        // dW1, first part (VALU): gzb (x) d1 and z (x) (r d1), d1 from E2
+        COOP_SYNC();                                                                    // (G) zs, gzbs visible; partial g read
+        ex_write(E0 + exW, dh1b);
+        COOP_SYNC();                                                                    // (I) E0 = dh1b, E1 = d2, E2 = d1
+        // dW2 += dh1b (x) d2, and in the shadow of its MFMAs the first part of dW1 on the VALU: gzb (x) d1 and z (x) (r d1), d1 from E2
         using f32x4 = __attribute__((ext_vector_type(4))) float;
         using LP4 = const __attribute__((address_space(3))) f32x4*;
         LPc d1p = E2 + fW1 * kExLd + sW1, rp1 = rsp + sW1;
         const LP4 gz4 = (LP4)(gzbsp + sW1 * NP), zz4 = (LP4)(zsp + sW1 * NP);
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const float d = d1p[s];
-            const float rd = rp1[s] * d;
+        auto w1_part1 = [&](int s2) __attribute__((always_inline)) {
+#if !defined(HJBX_COOP_NO_W1) && !defined(HJBX_COOP_NO_FILL1)
+            const float d = d1p[s2];
+            const float rd = rp1[s2] * d;
+            const f32x2 d2v{d, d}, rd2v{rd, rd};
 #pragma unroll
             for (int k4 = 0; k4 < NP / 4; ++k4) {
-                const f32x4 gz = gz4[s * (NP / 4) + k4];
-                const f32x4 zz = zz4[s * (NP / 4) + k4];
-                const float gv[4] = {gz[0], gz[1], gz[2], gz[3]}, zv[4] = {zz[0], zz[1], zz[2], zz[3]};
+                const f32x4 gz = gz4[s2 * (NP / 4) + k4];
+                const f32x4 zz = zz4[s2 * (NP / 4) + k4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (4 * k4 + c < N) { w1h[4 * k4 + c] += gv[c] * d; w1t[4 * k4 + c] += zv[c] * rd; }
+                for (int c = 0; c < 2; ++c)
+                    if (4 * k4 + 2 * c < N) {
+                        w1h[2 * k4 + c] = __builtin_elementwise_fma(f32x2{gz[2 * c], gz[2 * c + 1]}, d2v, w1h[2 * k4 + c]);
+                        w1t[2 * k4 + c] = __builtin_elementwise_fma(f32x2{zz[2 * c], zz[2 * c + 1]}, rd2v, w1t[2 * k4 + c]);
+                    }
             }
-        }
-        __syncthreads();                                                                    // (H) d1 read: E2 may be overwritten
-        ex_write(E0 + exW, dh1b);
-        ex_write(E2 + exW, h1r);
-        __syncthreads();                                                                    // (I) E0 = dh1b, E2 = h1, E1 = d2
-        coop_outer<4, true, true>(acc2h, E0, E1, acc2t, E2, E1, rsp, exA, exO, h);              // dW2 += dh1b (x) d2;  dW2_t += h1 (x) (r d2)
+            // pin the slice HERE: fma is a pure operation, and instruction selection sinks pure operations towards their use -- the store at
+            // the end of the kernel -- so all sixteen slices' loaded operands (26 registers each) stayed live and 330 registers spilled
+#pragma unroll
+            for (int k = 0; k < N / 2; ++k) asm volatile("" : "+v"(w1h[k]), "+v"(w1t[k]));
+#endif
+        };
+#ifdef HJBX_COOP_NO_OUTER
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) w1_part1(s2);
+#endif
+        COOP_OUTER(coop_outer<4, true, false>(acc2h, E0, E1, acc2t, E0, E1, rsp, exA, exO, h, w1_part1);)
         // ---- 7. t2 = W2'dh1b, dh2b = t2.s2 -------------------------------------------------------------------------------------------------
         zero16(acc);
-        coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));
+        COOP_CHAIN(coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));)
         f32x16 c2r;
         f32x16 dh2b;
 #pragma unroll
@@ -359,16 +452,19 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
             if constexpr (ACT == HJBX_ACT_TANH) c2r[r] = -2.f * h2r[r] * d2r[r] * acc[r];
             dh2b[r] = dact1<ACT>(h2r[r], acc[r]);
         }
-        __syncthreads();                                                                    // (J) the outer products above have read E1, E2
+        COOP_SYNC();                                                                    // (J) the outer products above have read E1; d1 (E2) is used up
         ex_write(E1 + exW, dh2b);
         if (kh == 0) ex_write(E2 + exWy, dyr);
-        __syncthreads();                                                                    // (K) E1 = dh2b, E2[0:64] = dy
-        coop_outer<2, true, false>(acc3h, E1, E2, acc3t, E1, E2, rsp, exA, exO, h);    // dW3 += dh2b (x) dy
+        COOP_SYNC();                                                                    // (K) E1 = dh2b, E2[0:64] = dy
+        COOP_OUTER(coop_outer<2, true, false>(acc3h, E1, E2, acc3t, E1, E2, rsp, exA, exO, h);)    // dW3 += dh2b (x) dy
+        // the next tile's inputs: issued here, not at the top of the tile -- their N + 2 registers would be live through the phases with the
+        // highest register pressure (steps 4-7), and three phases (~3 us) still cover the HBM latency
+        fetch(tile + gridDim.x, xs_n, dn_n, cst_n);
         // ---- 8. yb = 2 W3'dh2b (halves summed through E0) ------------------------------------------------------------------------------------
         zero16(acc);
-        coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));
+        COOP_CHAIN(coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));)
         if (kh == 1) ex_write(E0 + exWy, acc);                                              // (dh1b's readers, chain 7, finished before (J))
-        __syncthreads();                                                                    // (L) E0[0:64] = the upper half's partial
+        COOP_SYNC();                                                                    // (L) E0[0:64] = the upper half's partial
         if (kh == 0) {
             ex_add(acc, E0 + exWy);
 #pragma unroll
@@ -376,47 +472,55 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
             ex_write(E0 + exWy, acc);                                                       // (each wave rewrites exactly the rows it has just read)
         }
         ex_write(E1 + exW, h2r);                                                            // (dh2b's readers, the outer products and chain 8, are past (L))
-        __syncthreads();                                                                    // (M) E0[0:64] = yb, E1 = h2, E2[0:64] = dy
-        coop_outer<2, true, true>(acc3h, E1, E0, acc3t, E1, E2, rsp, exA, exO, h);              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
+        COOP_SYNC();                                                                    // (M) E0[0:64] = yb, E1 = h2, E2[0:64] = dy
+        COOP_OUTER(coop_outer<2, true, true>(acc3h, E1, E0, acc3t, E1, E2, rsp, exA, exO, h);)              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
         // ---- 9. a2b = (W3 yb).s2 [+ c2] ------------------------------------------------------------------------------------------------------
         zero16(acc);
-        coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));
+        COOP_CHAIN(coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));)
         f32x16 a2b;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             a2b[r] = dact1<ACT>(h2r[r], acc[r]);
             if constexpr (ACT == HJBX_ACT_TANH) a2b[r] += c2r[r];
         }
-        __syncthreads();                                                                    // (N) the outer products above have read E1, E2
+        COOP_SYNC();                                                                    // (N) the outer products above have read E1, E2
         ex_write(E2 + exW, a2b);
         ex_write(E1 + exW, h1r);
-        __syncthreads();                                                                    // (O) E2 = a2b, E1 = h1
-        coop_outer<4, true, false>(acc2h, E1, E2, acc2t, E1, E2, rsp, exA, exO, h);    // dW2 += h1 (x) a2b
+        ex_write(E0 + exW, d2r);                                                            // (yb's readers, chain 9 and the outer products, finished before (N))
+        COOP_SYNC();                                                                    // (O) E2 = a2b, E1 = h1, E0 = d2
+        COOP_OUTER(coop_outer<4, true, true>(acc2h, E1, E2, acc2t, E1, E0, rsp, exA, exO, h);)     // dW2 += h1 (x) a2b;  dW2_t += h1 (x) (r d2)
         // ---- 10. a1b = (W2 a2b).s1 [+ c1]; dW1 second part ----------------------------------------------------------------------------------
         zero16(acc);
-        coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E2 + exB));
+        COOP_CHAIN(coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E2 + exB));)
         f32x16 a1b;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             a1b[r] = dact1<ACT>(h1r[r], acc[r]);
             if constexpr (ACT == HJBX_ACT_TANH) a1b[r] += c1r[r];
         }
-        ex_write(E0 + exW, a1b);                                                            // (yb's readers, chain 9 and the outer products, finished before (N))
-        __syncthreads();                                                                    // (P) E0 = a1b
-        LPc a1p = E0 + fW1 * kExLd + sW1;
+        COOP_SYNC();                                                                    // (P) chain 10 and the outer products above have read E0, E1, E2
+        ex_write(E2 + exW, a1b);   // read -- as the second part of dW1, z (x) a1b -- in the shadow of the NEXT tile's chain 2 (visible after its (A)), or below
+    }
+    COOP_SYNC();
+    {   // the last tile's z (x) a1b
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        using LP4 = const __attribute__((address_space(3))) f32x4*;
+        LPc a1p = E2g + fW1 * kExLd + sW1;
+        const LP4 zz4 = (LP4)(zsg + sW1 * NP);
+#ifndef HJBX_COOP_NO_W1
 #pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const float a = a1p[s];
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float a = a1p[s2];
+            const f32x2 a2v{a, a};
 #pragma unroll
             for (int k4 = 0; k4 < NP / 4; ++k4) {
-                const f32x4 zz = zz4[s * (NP / 4) + k4];
-                const float zv[4] = {zz[0], zz[1], zz[2], zz[3]};
+                const f32x4 zz = zz4[s2 * (NP / 4) + k4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (4 * k4 + c < N) w1h[4 * k4 + c] += zv[c] * a;
+                for (int c = 0; c < 2; ++c)
+                    if (4 * k4 + 2 * c < N) w1h[2 * k4 + c] = __builtin_elementwise_fma(f32x2{zz[2 * c], zz[2 * c + 1]}, a2v, w1h[2 * k4 + c]);
             }
         }
-        __syncthreads();                                                                    // (Q) the tile's images and small arrays are free again
+#endif
     }
     // ---- partial sums of this workgroup (added in workgroup order by k_train_coop_reduce: deterministic, no float atomics) ------------------
     float* out = partial + (int64_t)blockIdx.x * kCoopBlocks * 1024;
@@ -430,8 +534,10 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     for (int j = 0; j < 2; ++j) { put(16 + w * 2 + j, acc3h[j]); put(kCoopSet + 16 + w * 2 + j, acc3t[j]); }
     float* o1 = partial_w1 + ((int64_t)blockIdx.x * 2 + (tid >> 7)) * (2 * N * 128);
 #pragma unroll
-    for (int k = 0; k < N; ++k) { o1[k * 128 + fW1] = w1h[k]; o1[(N + k) * 128 + fW1] = w1t[k]; }
-    if (w == 0) {   // loss sums and counts: lanes -> wave (fixed shuffle tree) -> one record
+    for (int k = 0; k < N; ++k) { o1[k * 128 + fW1] = w1h[k >> 1][k & 1]; o1[(N + k) * 128 + fW1] = w1t[k >> 1][k & 1]; }
+    if (w == 0) {   // loss sums and counts: sample slots -> wave (fixed shuffle tree) -> one record
+        double acc_h = h == 0 ? L.sums[0][i] : 0.0, acc_t = h == 0 ? L.sums[1][i] : 0.0;
+        double acc_ni = h == 0 ? L.sums[2][i] : 0.0, acc_nd = h == 0 ? L.sums[3][i] : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             acc_h += __shfl_down(acc_h, off, 64); acc_t += __shfl_down(acc_t, off, 64);
@@ -548,11 +654,15 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
 int hjbx_train_coop(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost, const float* done,
                     float* flat, void* workspace, int64_t B, void* stream) {
     int rc = HJBX_EUNSUPPORTED;
-#ifdef HJBX_TRAIN_DEV   // development builds: cartpole only
+#ifdef HJBX_TRAIN_DEV   // development builds: cartpole and the 10-D quadcopter only
     bool ok = false;
     if (sys->kind == HJBX_SYS_CARTPOLE) {
         Cartpole<float> cp{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
         rc = launch_coop<Cartpole<float>>(sys, cp, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+        ok = true;
+    } else if (sys->kind == HJBX_SYS_NEARHOVER) {
+        NearHover<float> q{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
+        rc = launch_coop<NearHover<float>>(sys, q, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
         ok = true;
     }
 #else

@@ -271,9 +271,13 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S", "--cuda-device-only",
                                    "-fno-slp-vectorize", "-o", str(train_asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_train.hip")],
                                   stderr=subprocess.DEVNULL))
+    coop_asm = tmp_path / "train_coop.s"
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S", "--cuda-device-only",
+                                   "-fno-slp-vectorize", "-o", str(coop_asm), os.path.join(ROOT, "q_learning_with_hjb_amd", "csrc", "hjbx_train_coop.hip")],
+                                  stderr=subprocess.DEVNULL))
     for pr in procs:
         assert pr.wait() == 0
-    for asm in outs + [train_asm]:
+    for asm in outs + [train_asm, coop_asm]:
         assert audit_asm_loads.audit(str(asm)) == 0
         # the other direction (round 2's planar-quadrotor bug class): no inline-asm VALU statement reads an MFMA result still in flight
         assert audit_asm_loads.audit_mfma_asm_reads(str(asm)) == 0
@@ -306,6 +310,14 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     assert "Folded Spill" not in text and "Folded Reload" not in text
     for name, _private, _sgpr_spill, vgpr_spill in meta.findall(text):
         assert int(vgpr_spill) == 0, f"{name}: {vgpr_spill} spilled VGPRs"
+    # the cooperative parameter-gradient kernel: 512 registers per wave (one wave per SIMD), its 192 outer-product accumulators in AGPRs,
+    # and NO scratch (its first build hoisted ~200 loop-invariant LDS addresses out of the tile loop and spilled 78 of them)
+    text = coop_asm.read_text()
+    kernels = [k for k in meta.findall(text) if "k_train_coop" in k[0] and "reduce" not in k[0]]
+    assert len(kernels) == 9 * 4, len(kernels)                 # 9 system instantiations x 2 residual modes x 2 activations
+    for name, private, _sgpr_spill, vgpr_spill in kernels:
+        assert int(private) == 0 and int(vgpr_spill) == 0, f"{name}: {private} bytes of scratch, {vgpr_spill} spilled VGPRs"
+    assert text.count("v_mfma_f32_32x32x2_f32") >= 36 * 690
 
 
 def test_graft_entry_build_check_passes():
