@@ -369,8 +369,28 @@ def optimiser_step(world, dist, system="cartpole", total=256):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    fit = None
+    if ctl._fit_graph_usable() and per_rank <= 4096:
+        # the same update as train() issues it (vhjb.py:314-324): minibatch selection, regularisation schedule and loss sums on the device,
+        # one graph replay per update, one read-back per epoch
+        rb = ctl.replay_buffer
+        nbt = min(rb.capacity // per_rank, 400)
+        while rb.size < nbt * per_rank:
+            k = min(wl["x0"].shape[0], nbt * per_rank - rb.size)
+            rb.extend(wl["x0"][:k], torch.rand(k, generator=gen, device="cuda") * 5, (torch.rand(k, generator=gen, device="cuda") < 0.1).float())
+        nbt = rb.size // per_rank
+        ctl._fit_epoch_graphed(per_rank, nbt)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            ctl._fit_epoch_graphed(per_rank, nbt)               # ends with the read-back of the loss sums: synchronous
+            ts.append((time.perf_counter() - t1) / nbt)
+        fit = dict(updates_per_epoch=nbt, ms_per_update=float(np.median(ts)) * 1e3, updates_per_s=1.0 / float(np.median(ts)),
+                   what="VHJBController.train's fit phase: one hipGraph replay per update (gather -> parameter gradient -> mix -> Adam), per-epoch "
+                        "host work (permutation, schedule table, loss read-back) included")
     return dict(name=f"params_update ({system}, {total} samples in total)", ranks=world, samples_per_rank=per_rank, updates_per_s=R / dt,
-                samples_per_s=R * per_rank * world / dt, ms_per_update=dt / R * 1e3,
+                samples_per_s=R * per_rank * world / dt, ms_per_update=dt / R * 1e3, fit_phase=fit,
                 gradient=("fused MFMA kernels (hjbx_value_loss_grad_f32)" if ctl.fused_param_grad else "PyTorch autograd"),
                 mode=("hipGraph replay" if ctl.graph_updates else "eager launches" + (" + one flat all-reduce" if world > 1 else "")))
 

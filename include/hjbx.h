@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 106 /* major*100 + minor */
+#define HJBX_VERSION 107 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -342,9 +342,38 @@ int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, cons
 
 /* The step between that buffer (after the all-reduce, if any) and Adam: mixed[k] = flat[k] / (#interior + eps) + reg * flat[P + k] / (#done + eps)
  * for the P = n_params parameter entries (vhjb.py:241, 253, 284) and losses[0..2] = {hjb + reg termination, hjb, termination} (vhjb.py:285-288;
- * losses may be NULL).  reg is read from reg_dev[0] when reg_dev is non-NULL (a device scalar survives hipGraph replay), else from `reg`. */
+ * losses may be NULL).  reg is read from reg_dev[0] when reg_dev is non-NULL (a device scalar survives hipGraph replay), else from `reg`.
+ * loss_accum (3 floats, may be NULL): the three losses are ADDED to it -- `total_losses += ...` of train (vhjb.py:320-322) on the device;
+ * step_counter (one int32, may be NULL): incremented by one -- `update_counter += 1` (vhjb.py:323). */
 int hjbx_mix_gradients_f32(const float* flat, int64_t n_params, const float* reg_dev, double reg, double eps, float* mixed, float* losses,
-                           void* stream);
+                           float* loss_accum, int32_t* step_counter, void* stream);
+
+/* The same step with optax.adam (vhjb.py:120, 262-263: b1, b2, eps as given, eps_root 0) applied in the same launch, the mixed gradient never
+ * materialised:  g as above;  m <- m + (1 - b1)(g - m);  v <- b2 v + (1 - b2) g^2;  t <- t + 1;
+ *                w <- w - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+ * param / exp_avg / exp_avg_sq: the three weight matrices W1, W2, W3 (row-major, numel[i] entries, in the order of `flat`) and Adam's moments,
+ * all updated in place; step[i]: device scalar holding t as float32, one per tensor (the layout torch.optim.Adam(fused / capturable) keeps, so
+ * its state tensors can be handed over as they are; t is read from step[0], t + 1 written to all three, which may alias); ticket: one zero-initialised device word for the kernel's use, left zero. */
+typedef struct hjbx_adam_state {
+    float* param[3];
+    float* exp_avg[3];
+    float* exp_avg_sq[3];
+    int64_t numel[3];
+    float* step[3];
+    unsigned int* ticket;
+    double lr, beta1, beta2, eps;
+} hjbx_adam_state;
+int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses, float* loss_accum,
+                      int32_t* step_counter, void* stream);
+
+/* The minibatch of one update, assembled on the device: DataLoader(batch_size, shuffle=True, drop_last=True) + np_collate of the reference
+ * (vhjb.py:151-154, 314; utils/utils.py:7-14) for a device-resident replay buffer (buf_x (capacity, n), buf_cost, buf_done (capacity,)):
+ *   xs[s] = buf_x[perm[k * batch + s]] (likewise costs, dones), s = 0..batch-1, with k = step_dev[0] read ON THE DEVICE (NULL: k = 0), and
+ *   reg_out[0] = reg_table[k] when reg_out is non-NULL (the regularisation weight of update k of the epoch, vhjb.py:323-324).
+ * perm: int32 row indices (one random permutation of the buffer per epoch).  With step_dev = the counter hjbx_mix_gradients_f32 increments, a
+ * captured hipGraph of gather -> hjbx_value_loss_grad_f32 -> mix -> Adam replays with no host-side work between two updates. */
+int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost, const float* buf_done, int n, const int32_t* perm, const int32_t* step_dev,
+                           const float* reg_table, int64_t batch, float* xs, float* costs, float* dones, float* reg_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,10 +39,17 @@ _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=3", "-fno-slp-vectorize"), "hjbx_mlp_h2.o"),
           ("hjbx_train.hip", ("-fno-slp-vectorize",), "hjbx_train.o"),
           ("hjbx_train_coop.hip", ("-fno-slp-vectorize",), "hjbx_train_coop.o"),
+          ("hjbx_fit.hip", (), "hjbx_fit.o"),
           ("hjbx_user.hip", (f'-DHJBX_CSRC_DIR="{_CSRC}"',), "hjbx_user.o"))       # embeds three headers as text for hiprtc (.incbin)
 _SOURCES = tuple(dict.fromkeys(u[0] for u in _UNITS))
 _HEADERS = ("hjbx_systems.hpp", "hjbx_internal.hpp", "hjbx_host.hpp", "hjbx_mlp_core.hpp", "hjbx_mlp_x3.hpp", "hjbx_mlp_h2.hpp", "hjbx_stream_kernels.hpp",
             "hjbx_user_kernels.hpp", os.path.join("..", "..", "include", "hjbx.h"))
+
+
+class HjbxAdamState(C.Structure):
+    """struct hjbx_adam_state"""
+    _fields_ = [("param", C.c_void_p * 3), ("exp_avg", C.c_void_p * 3), ("exp_avg_sq", C.c_void_p * 3), ("numel", C.c_int64 * 3),
+                ("step", C.c_void_p * 3), ("ticket", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
 
 
 class HjbxTask(C.Structure):
@@ -204,7 +211,7 @@ EXPORTED_SYMBOLS = (
     ["hjbx_version", "hjbx_last_error", "hjbx_device_count", "hjbx_set_option", "hjbx_system_create", "hjbx_system_create_from_source",
      "hjbx_last_compile_log", "hjbx_system_destroy", "hjbx_dims",
      "hjbx_reduce_workspace_bytes", "hjbx_rollout_workspace_bytes", "hjbx_value_grad_f32", "hjbx_vhjb_rollout_f32",
-     "hjbx_value_loss_grad_workspace_bytes", "hjbx_value_loss_grad_f32", "hjbx_mix_gradients_f32"]
+     "hjbx_value_loss_grad_workspace_bytes", "hjbx_value_loss_grad_f32", "hjbx_mix_gradients_f32", "hjbx_mix_adam_f32", "hjbx_replay_gather_f32"]
     + [f"hjbx_{k}_{s}" for k in _typed_signatures() for s in ("f32", "f64")]
 )
 
@@ -253,7 +260,11 @@ def lib() -> C.CDLL:
         L.hjbx_value_loss_grad_f32.restype = C.c_int
         L.hjbx_value_loss_grad_f32.argtypes = [_VP, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, _I64, _VP]
         L.hjbx_mix_gradients_f32.restype = C.c_int
-        L.hjbx_mix_gradients_f32.argtypes = [_VP, _I64, _VP, _DBL, _DBL, _VP, _VP, _VP]
+        L.hjbx_mix_gradients_f32.argtypes = [_VP, _I64, _VP, _DBL, _DBL, _VP, _VP, _VP, _VP, _VP]
+        L.hjbx_mix_adam_f32.restype = C.c_int
+        L.hjbx_mix_adam_f32.argtypes = [_VP, _VP, _DBL, _DBL, C.POINTER(HjbxAdamState), _VP, _VP, _VP, _VP]
+        L.hjbx_replay_gather_f32.restype = C.c_int
+        L.hjbx_replay_gather_f32.argtypes = [_VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")

@@ -302,8 +302,9 @@ def release_workspaces(stream=None):
             del cache[key]
 
 
-def mix_gradients(flat, n_params, regularization, eps):
-    """hjbx_mix_gradients_f32: -> (mixed (P,), losses (3,) = [total, hjb, termination]).  `regularization`: float or 0-dim float32 CUDA tensor."""
+def mix_gradients(flat, n_params, regularization, eps, loss_accum=None, step_counter=None):
+    """hjbx_mix_gradients_f32: -> (mixed (P,), losses (3,) = [total, hjb, termination]).  `regularization`: float or 0-dim float32 CUDA tensor.
+    loss_accum (3,) float32: the losses are added to it on the device; step_counter (1,) int32: incremented on the device."""
     _chk(flat, "flat", (2 * n_params + 4,), torch.float32)
     mixed = torch.empty((n_params,), dtype=torch.float32, device=flat.device)
     losses = torch.empty((3,), dtype=torch.float32, device=flat.device)
@@ -312,5 +313,51 @@ def mix_gradients(flat, n_params, regularization, eps):
         reg_dev, reg = _p(regularization), 0.0
     else:
         reg_dev, reg = None, float(regularization)
-    check(lib().hjbx_mix_gradients_f32(_p(flat), int(n_params), reg_dev, reg, float(eps), _p(mixed), _p(losses), _stream()))
+    if loss_accum is not None:
+        _chk(loss_accum, "loss_accum", (3,), torch.float32)
+    if step_counter is not None:
+        _chk(step_counter, "step_counter", (1,), torch.int32)
+    check(lib().hjbx_mix_gradients_f32(_p(flat), int(n_params), reg_dev, reg, float(eps), _p(mixed), _p(losses), _p(loss_accum), _p(step_counter), _stream()))
     return mixed, losses
+
+
+def mix_adam(flat, regularization, eps, params, exp_avgs, exp_avg_sqs, steps, ticket, lr, beta1, beta2, adam_eps, loss_accum=None, step_counter=None):
+    """hjbx_mix_adam_f32: mix of the two gradients + one Adam step on the three weight matrices, in place, one launch.  -> losses (3,)"""
+    P = sum(p.numel() for p in params)
+    _chk(flat, "flat", (2 * P + 4,), torch.float32)
+    st = _abi.HjbxAdamState()
+    for i, (p, m, v, k) in enumerate(zip(params, exp_avgs, exp_avg_sqs, steps)):
+        for t, nm in ((p, "param"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _chk(t, nm, tuple(p.shape), torch.float32)
+        _chk(k, "step", (), torch.float32)
+        st.param[i], st.exp_avg[i], st.exp_avg_sq[i], st.numel[i], st.step[i] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), k.data_ptr()
+    _chk(ticket, "ticket", (1,), torch.int32)
+    st.ticket = ticket.data_ptr()
+    st.lr, st.beta1, st.beta2, st.eps = float(lr), float(beta1), float(beta2), float(adam_eps)
+    losses = torch.empty((3,), dtype=torch.float32, device=flat.device)
+    if torch.is_tensor(regularization):
+        _chk(regularization, "regularization", (), torch.float32)
+        reg_dev, reg = _p(regularization), 0.0
+    else:
+        reg_dev, reg = None, float(regularization)
+    if loss_accum is not None:
+        _chk(loss_accum, "loss_accum", (3,), torch.float32)
+    if step_counter is not None:
+        _chk(step_counter, "step_counter", (1,), torch.int32)
+    check(lib().hjbx_mix_adam_f32(_p(flat), reg_dev, reg, float(eps), C.byref(st), _p(losses), _p(loss_accum), _p(step_counter), _stream()))
+    return losses
+
+
+def replay_gather(buf_x, buf_cost, buf_done, perm, step_counter, reg_table, xs, costs, dones, reg_out):
+    """hjbx_replay_gather_f32: minibatch number step_counter[0] (read on the device) of the epoch's permutation into xs / costs / dones, and the
+    regularisation weight of that update into reg_out (0-dim float32)."""
+    batch, n = xs.shape
+    _chk(buf_x, "buf_x", (buf_x.shape[0], n), torch.float32)
+    _chk(perm, "perm", (perm.shape[0],), torch.int32)
+    _chk(step_counter, "step_counter", (1,), torch.int32)
+    _chk(costs, "costs", (batch,), torch.float32)
+    _chk(dones, "dones", (batch,), torch.float32)
+    _chk(reg_out, "reg_out", (), torch.float32)
+    _chk(reg_table, "reg_table", (reg_table.shape[0],), torch.float32)
+    check(lib().hjbx_replay_gather_f32(_p(buf_x), _p(buf_cost), _p(buf_done), int(n), _p(perm), _p(step_counter), _p(reg_table), int(batch), _p(xs), _p(costs),
+                                       _p(dones), _p(reg_out), _stream()))

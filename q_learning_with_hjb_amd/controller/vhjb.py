@@ -319,6 +319,7 @@ class VHJBController(Controller):
             graph_updates = self.device.type == "cuda" and not self._distributed() and os.environ.get("HJBX_GRAPH_UPDATES", "1") != "0"
         self.graph_updates = bool(graph_updates)
         self._graphed_update = None
+        self._fit_graph = None
         self._reg_buf = None
         # optax.adam(lr) (vhjb.py:120): b1 0.9, b2 0.999, eps 1e-8.  On the device the fused implementation (one kernel for the three
         # weight matrices instead of ~10 foreach launches); HJBX_FUSED_ADAM=0 or a PyTorch without it falls back to the default
@@ -329,8 +330,13 @@ class VHJBController(Controller):
                 self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), fused=True, **adam_kw)
             except (RuntimeError, TypeError, ValueError):
                 self.optimizer = None
+        fused_adam = self.optimizer is not None
         if self.optimizer is None:
             self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), **adam_kw)
+        # on the fused parameter-gradient path the Adam step rides in the library's mix kernel (hjbx_mix_adam_f32), working on this
+        # optimiser's state tensors in place: the other paths (autograd, HJBX_FUSED_ADAM=0) and state_dict() see one and the same state
+        self._native_adam = self.fused_param_grad and fused_adam
+        self._adam_ticket = torch.zeros((1,), dtype=torch.int32, device=self.device) if self._native_adam else None
         self._sched = dict(init_value=config.regularization_init_value, peak_value=config.regularization_peak_value,
                            end_value=config.regularization_end_value, warmup_steps=config.regularization_warmup_steps_per_cycle,
                            decay_steps=config.regularization_total_steps_per_cycle, num_cycles=config.regularization_num_of_cycles)
@@ -553,15 +559,34 @@ class VHJBController(Controller):
             torch.distributed.all_reduce(flat, group=self.process_group)
         return flat
 
-    def _update_core(self, xs, dones, costs, regularization):
-        """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph."""
+    def _adam_state(self, params):
+        """(exp_avg list, exp_avg_sq list, step list) of torch.optim.Adam for the three weight matrices, created the way its fused implementation
+        creates them if no step has run yet (zeros; the step counts float32 device scalars)."""
+        st = self.optimizer.state
+        for p in params:
+            if len(st[p]) == 0:
+                st[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return [st[p]["exp_avg"] for p in params], [st[p]["exp_avg_sq"] for p in params], [st[p]["step"] for p in params]
+
+    def _update_core(self, xs, dones, costs, regularization, loss_accum=None, step_counter=None):
+        """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph.  loss_accum / step_counter
+        (fused path only): device-side `total_losses += ...` and `update_counter += 1` of train (vhjb.py:320-323)."""
         model_params = list(self.value_function_approximator.parameters())
         if self.fused_param_grad:
             # one C-ABI call: [d sum(hjb)/dW | d sum(termination)/dW | sum hjb, sum termination, #interior, #done] -- exactly the buffer
             # the data-parallel step all-reduces once; then the division by the (global) counts and the mix (vhjb.py:241, 253, 284)
             flat = self.value_loss_gradient(xs, dones, costs)
+            if self._native_adam:
+                # counts, mix, the three losses AND optax.adam's step (vhjb.py:120, 262-263) in one launch, on the optimiser's own state tensors
+                m, v, step = self._adam_state(model_params)
+                g = self.optimizer.param_groups[0]
+                losses = _ops.mix_adam(flat, regularization, self.epsilon, [p.data for p in model_params], m, v, step, self._adam_ticket, g["lr"],
+                                       g["betas"][0], g["betas"][1], g["eps"], loss_accum, step_counter)
+                return losses[0], losses[1], losses[2]
             P = sum(p.numel() for p in model_params)
-            mixed, losses = _ops.mix_gradients(flat, P, regularization, self.epsilon)     # counts, mix and the three losses in one launch
+            mixed, losses = _ops.mix_gradients(flat, P, regularization, self.epsilon, loss_accum, step_counter)   # counts, mix, losses: one launch
             grads, off = [], 0
             for p in model_params:
                 grads.append(mixed[off:off + p.numel()].view_as(p))
@@ -610,6 +635,36 @@ class VHJBController(Controller):
                                                (xs, dones, costs, self._reg_buf))
         return self._graphed_update(xs, dones, costs, self._reg_buf)
 
+    # -- the fit phase of one epoch, driven from the device ------------------------------------------------
+    def _fit_graph_usable(self) -> bool:
+        """One process, the fused float32 parameter gradient, graphs enabled, and params_update not replaced by a subclass or a test double
+        (those keep the per-minibatch loop, which calls params_update like the reference does, vhjb.py:314-319)."""
+        return (self.graph_updates and self.fused_param_grad and not self._distributed() and self.device.type == "cuda"
+                and "params_update" not in self.__dict__ and type(self).params_update is VHJBController.params_update
+                and type(self)._update_core is VHJBController._update_core)
+
+    def _fit_epoch_graphed(self, batch: int, nb: int):
+        """`for xs, costs, dones in dataloader: params_update(...)` of train (vhjb.py:314-324) with every per-update decision taken on the device:
+        minibatch k = rows perm[k batch .. (k + 1) batch) of the replay buffer, gathered by hjbx_replay_gather_f32 with k read from a device
+        counter; the regularisation weight of update k read from a table of the schedule uploaded once per epoch; the three running loss sums
+        and the counter advanced by hjbx_mix_gradients_f32.  The host replays ONE hipGraph (gather -> parameter gradient -> mix -> Adam) nb
+        times and reads the loss sums back once.  -> (sum total, sum hjb, sum termination) as floats."""
+        fg = self._fit_graph
+        if fg is None or fg.batch != batch:
+            fg = self._fit_graph = FitGraph(self, batch)
+        rb = self.replay_buffer
+        perm = torch.randperm(rb.size, device=self.device, generator=self._gen)       # the same draw as ReplayBuffer.batches
+        fg.perm[:rb.size].copy_(perm)
+        table = torch.tensor([self.regularization_scheduler(self.update_counter + k) for k in range(nb)], dtype=torch.float32)
+        fg.reg_table[:nb].copy_(table, non_blocking=False)
+        fg.step.zero_()
+        fg.loss_accum.zero_()
+        fg.replay(nb)
+        sums = fg.loss_accum.cpu().tolist()
+        self.update_counter += nb
+        self.regularization = self.regularization_scheduler(self.update_counter)
+        return sums[0], sums[1], sums[2]
+
     # -- training loop (vhjb.py:290-343) ---------------------------------------------------------------
     def train(self):
         average_trajectory_cost_list = []
@@ -641,17 +696,21 @@ class VHJBController(Controller):
                 nbt = torch.tensor([nb], device=self.device)
                 torch.distributed.all_reduce(nbt, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
                 nb = int(nbt.item())
-            # with a captured update graph the minibatch is gathered straight into the graph's static input buffers
-            gu = self._graphed_update if self.graph_updates else None
-            static = (gu.inputs[0], gu.inputs[2], gu.inputs[1]) if gu is not None and gu.inputs[0].shape[0] == per_rank_batch else None
-            for xs, costs, dones in self.replay_buffer.batches(per_rank_batch, generator=self._gen, limit=nb, out=static):
-                update = self.params_update_graphed if self.graph_updates else self.params_update
-                total_loss, hjb_loss, termination_loss = update(xs, dones, costs, self.regularization)
-                total_losses = total_losses + total_loss
-                hjb_losses = hjb_losses + hjb_loss
-                termination_losses = termination_losses + termination_loss
-                self.update_counter += 1
-                self.regularization = self.regularization_scheduler(self.update_counter)
+            if nb and self._fit_graph_usable():
+                # the whole fit phase driven from the device: ONE graph replay per update and nothing else on the host
+                total_losses, hjb_losses, termination_losses = self._fit_epoch_graphed(per_rank_batch, nb)
+            else:
+                # with a captured update graph the minibatch is gathered straight into the graph's static input buffers
+                gu = self._graphed_update if self.graph_updates else None
+                static = (gu.inputs[0], gu.inputs[2], gu.inputs[1]) if gu is not None and gu.inputs[0].shape[0] == per_rank_batch else None
+                for xs, costs, dones in self.replay_buffer.batches(per_rank_batch, generator=self._gen, limit=nb, out=static):
+                    update = self.params_update_graphed if self.graph_updates else self.params_update
+                    total_loss, hjb_loss, termination_loss = update(xs, dones, costs, self.regularization)
+                    total_losses = total_losses + total_loss
+                    hjb_losses = hjb_losses + hjb_loss
+                    termination_losses = termination_losses + termination_loss
+                    self.update_counter += 1
+                    self.regularization = self.regularization_scheduler(self.update_counter)
 
             if ntraj > 0:
                 average_trajectory_cost_list.append(float(traj_costs.sum() / ntraj))
@@ -685,29 +744,7 @@ class GraphedStep:
     def __init__(self, optimizer, params, core, example_inputs):
         self.inputs = [t.detach().clone() for t in example_inputs]
         self.shapes = [tuple(t.shape) for t in self.inputs]
-        dev = self.inputs[0].device
-        saved_p = [p.detach().clone() for p in params]
-        saved_s = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()} for p in params if p in optimizer.state}
-        # warm-up AND capture run on this one side stream: the library's workspaces (_ops: reduce tickets, rollout flags, the parameter-
-        # gradient scratch) are cached per (device, stream), so the buffers the warm-up allocated -- and zero-filled, outside any capture --
-        # are exactly the ones the captured launches use (capturing on torch's default capture stream allocated every workspace a second
-        # time, in the graph's pool, and recorded their zero-fill as memset nodes)
-        side = self._stream = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):                      # allocates Adam's state, rocBLAS workspaces and this library's workspaces
-                core(*self.inputs)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        with torch.no_grad():
-            for p, q in zip(params, saved_p):
-                p.copy_(q)
-                for k, v in optimizer.state[p].items():
-                    if torch.is_tensor(v):
-                        v.copy_(saved_s[p][k]) if p in saved_s else v.zero_()
-                p.grad = None
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self.out = core(*self.inputs)
+        self._stream, self.graph, self.out = capture_step(optimizer, params, lambda: core(*self.inputs), self.inputs[0].device)
 
     def __del__(self):
         # the workspaces cached for this step's private stream die with it (5 KB of scratch per sample for the parameter gradient)
@@ -727,6 +764,105 @@ class GraphedStep:
                 buf.copy_(t)
         self.graph.replay()
         return self.out
+
+
+def capture_step(optimizer, params, step_fn, dev, before_each=None):
+    """Warm `step_fn` up three times and capture it into a hipGraph, leaving parameters and optimiser state as they were.
+    -> (the private stream the graph was captured on, the graph, step_fn's captured outputs)"""
+    saved_p = [p.detach().clone() for p in params]
+    saved_s = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()} for p in params if p in optimizer.state}
+    # warm-up AND capture run on this one side stream: the library's workspaces (_ops: reduce tickets, rollout flags, the parameter-
+    # gradient scratch) are cached per (device, stream), so the buffers the warm-up allocated -- and zero-filled, outside any capture --
+    # are exactly the ones the captured launches use (capturing on torch's default capture stream allocated every workspace a second
+    # time, in the graph's pool, and recorded their zero-fill as memset nodes)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):                      # allocates Adam's state, rocBLAS workspaces and this library's workspaces
+            if before_each is not None:
+                before_each()
+            step_fn()
+        if before_each is not None:
+            before_each()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    with torch.no_grad():
+        for p, q in zip(params, saved_p):
+            p.copy_(q)
+            for k, v in optimizer.state[p].items():
+                if torch.is_tensor(v):
+                    v.copy_(saved_s[p][k]) if p in saved_s else v.zero_()
+            p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        out = step_fn()
+    return side, graph, out
+
+
+class FitGraph:
+    """The optimiser step of the fit phase with its minibatch selection inside the graph (VHJBController._fit_epoch_graphed):
+    hjbx_replay_gather_f32 -> hjbx_value_loss_grad_f32 -> hjbx_mix_adam_f32.  Static buffers: perm (replay capacity, int32), reg_table (one
+    entry per update of an epoch), step (device update counter within the epoch), loss_accum (3 running loss sums).  Because nothing on the
+    host changes between two updates, UNROLL consecutive updates are also captured as one graph: a launch of that graph pays the
+    graph-to-graph gap (about 8 us on MI355X) once per UNROLL updates."""
+
+    UNROLL = 8
+
+    def __init__(self, ctl, batch: int):
+        rb, dev = ctl.replay_buffer, ctl.device
+        assert rb.x.dtype == torch.float32
+        self.batch = int(batch)
+        n = rb.x.shape[1]
+        # zeros: the warm-up launches gather row 0; sized so that UNROLL warm-up updates stay inside
+        self.perm = torch.zeros((max(rb.capacity, self.UNROLL * batch),), dtype=torch.int32, device=dev)
+        self.reg_table = torch.zeros((rb.capacity // batch + self.UNROLL + 1,), dtype=torch.float32, device=dev)
+        self.step = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.loss_accum = torch.zeros((3,), dtype=torch.float32, device=dev)
+        self.xs = torch.empty((batch, n), dtype=torch.float32, device=dev)
+        self.costs = torch.empty((batch,), dtype=torch.float32, device=dev)
+        self.dones = torch.empty((batch,), dtype=torch.float32, device=dev)
+        self.reg = torch.zeros((), dtype=torch.float32, device=dev)
+        self._ctl_ref = ctl
+        self._streams, self._graphs = [], {}
+        self._capture(1)
+
+    def _one_update(self):
+        ctl, rb = self._ctl_ref, self._ctl_ref.replay_buffer
+        _ops.replay_gather(rb.x, rb.cost, rb.done, self.perm, self.step, self.reg_table, self.xs, self.costs, self.dones, self.reg)
+        return ctl._update_core(self.xs, self.dones, self.costs, self.reg, loss_accum=self.loss_accum, step_counter=self.step)
+
+    def _capture(self, count: int):
+        ctl = self._ctl_ref
+
+        def step_fn():
+            for _ in range(count):
+                out = self._one_update()
+            return out
+
+        saved = (self.step.clone(), self.loss_accum.clone())
+        stream, graph, out = capture_step(ctl.optimizer, list(ctl.value_function_approximator.parameters()), step_fn, ctl.device,
+                                          before_each=self.step.zero_)
+        self.step.copy_(saved[0])
+        self.loss_accum.copy_(saved[1])
+        self._streams.append(stream)
+        self._graphs[count] = (graph, out)
+
+    def replay(self, count: int):
+        if count >= self.UNROLL and self.UNROLL not in self._graphs:
+            self._capture(self.UNROLL)
+        many = self._graphs.get(self.UNROLL)
+        while many is not None and count >= self.UNROLL:
+            many[0].replay()
+            count -= self.UNROLL
+        for _ in range(count):
+            self._graphs[1][0].replay()
+
+    def __del__(self):
+        for st in getattr(self, "_streams", ()):
+            try:
+                _ops.release_workspaces(st.cuda_stream)
+            except Exception:
+                pass
+
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,152 @@
+// The small kernels of the fit phase around the parameter gradient (hjbx_train*.hip): the minibatch of one update gathered on the device,
+// the division by the counts + the mix of the two gradients, and the same with the Adam step applied in the same launch.
+//
+// reference: controller/vhjb.py:151-154, 314 (DataLoader, shuffle, drop_last), :241, 253, 284-288 (means, mix, losses), :120 and :262-263
+// (optax.adam(lr), optax.apply_updates), :320-324 (running loss sums, update counter, regularisation schedule).
+#include <hip/hip_runtime.h>
+
+#include "hjbx_internal.hpp"
+
+// ---- divide by the counts and mix (vhjb.py:241, 253, 284) --------------------------------------------------------------------------
+// mixed = g_h / (#interior + eps) + reg g_t / (#done + eps); losses = {hjb + reg termination, hjb, termination}.  One launch instead of the
+// dozen element-wise launches the same arithmetic costs in torch (at a minibatch of 256 the whole step is launch bound).
+__global__ __launch_bounds__(256) void k_mix_gradients(const float* __restrict__ flat, int64_t P, const float* __restrict__ reg_dev, float reg_host,
+                                                      float eps, float* __restrict__ mixed, float* __restrict__ losses, float* __restrict__ loss_accum,
+                                                      int32_t* __restrict__ step_counter) {
+    const float reg = reg_dev ? reg_dev[0] : reg_host;
+    const float ih = 1.0f / (flat[2 * P + 2] + eps), it = 1.0f / (flat[2 * P + 3] + eps);
+    const float wt = reg * it;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < P; k += (int64_t)gridDim.x * 256) mixed[k] = flat[k] * ih + flat[P + k] * wt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float h = flat[2 * P] * ih, t = flat[2 * P + 1] * it;
+        if (losses) { losses[0] = h + reg * t; losses[1] = h; losses[2] = t; }
+        if (loss_accum) { loss_accum[0] += h + reg * t; loss_accum[1] += h; loss_accum[2] += t; }   // total_losses += ... of train (vhjb.py:320-322)
+        if (step_counter) step_counter[0] += 1;                                                     // update_counter += 1 (vhjb.py:323)
+    }
+}
+
+extern "C" int hjbx_mix_gradients_f32(const float* flat, int64_t n_params, const float* reg_dev, double reg, double eps, float* mixed, float* losses,
+                                      float* loss_accum, int32_t* step_counter, void* stream) {
+    if (!flat || !mixed || n_params <= 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_gradients_f32: NULL buffer or non-positive parameter count");
+    const int grid = (int)((n_params + 255) / 256 < 512 ? (n_params + 255) / 256 : 512);
+    hipLaunchKernelGGL(k_mix_gradients, dim3(grid), dim3(256), 0, (hipStream_t)stream, flat, n_params, reg_dev, (float)reg, (float)eps, mixed, losses, loss_accum,
+                       step_counter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_mix_gradients_f32: %s", hipGetErrorString(e));
+    return HJBX_OK;
+}
+
+// ---- the minibatch of one update, assembled on the device ---------------------------------------------------------------------------------
+// DataLoader(batch_size, shuffle=True, drop_last=True) + np_collate of the reference (vhjb.py:151-154, 314; utils/utils.py:7-14) for the
+// device-resident replay buffer: minibatch k of an epoch is rows perm[k batch .. (k + 1) batch) of the buffer.  k is read from DEVICE memory
+// (the counter hjbx_mix_gradients_f32 increments) and so is the regularisation weight of that update (a per-epoch table of the schedule,
+// vhjb.py:323-324): a captured hipGraph of gather -> gradient -> mix -> Adam replays with NO host-side work between two updates.
+__global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__ bx, const float* __restrict__ bc, const float* __restrict__ bd, int n,
+                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ step, const float* __restrict__ reg_table,
+                                                      int64_t batch, float* __restrict__ ox, float* __restrict__ oc, float* __restrict__ od,
+                                                      float* __restrict__ oreg) {
+    const int64_t k = step ? (int64_t)step[0] : 0;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0 && oreg && reg_table) oreg[0] = reg_table[k];
+    if (t >= batch * n) return;
+    const int64_t smp = t / n;
+    const int c = (int)(t - smp * n);
+    const int64_t row = perm[k * batch + smp];
+    ox[t] = bx[row * n + c];
+    if (c == 0) { oc[smp] = bc[row]; od[smp] = bd[row]; }
+}
+
+extern "C" int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost, const float* buf_done, int n, const int32_t* perm, const int32_t* step_dev,
+                                      const float* reg_table, int64_t batch, float* xs, float* costs, float* dones, float* reg_out, void* stream) {
+    if (!buf_x || !buf_cost || !buf_done || !perm || !xs || !costs || !dones)
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_replay_gather_f32: NULL buffer");
+    if (n < 1 || n > HJBX_MAX_N || batch < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_replay_gather_f32: bad n or batch");
+    if (reg_out && !reg_table) return hjbx_set_error(HJBX_EINVAL, "hjbx_replay_gather_f32: reg_out needs reg_table");
+    if (batch == 0) return HJBX_OK;
+    const int64_t nthreads = batch * n;
+    hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, buf_x, buf_cost, buf_done, n, perm, step_dev,
+                       reg_table, batch, xs, costs, dones, reg_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_replay_gather_f32: %s", hipGetErrorString(e));
+    return HJBX_OK;
+}
+
+// ---- mix + Adam in one launch -------------------------------------------------------------------------------------------------------------
+// optax.adam(lr) of the reference (vhjb.py:120: b1 0.9, b2 0.999, eps 1e-8, eps_root 0) applied to the mixed gradient without materialising it:
+//   g = flat[k] / (#interior + eps) + reg flat[P + k] / (#done + eps)
+//   m <- m + (1 - b1) (g - m);  v <- b2 v + (1 - b2) g^2;  t <- t + 1
+//   w <- w - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps_adam)
+// (the form torch's fused Adam evaluates, so the state tensors of a torch.optim.Adam can be handed over as they are).  At the reference's
+// minibatch the update is launch bound: this replaces the mix kernel and Adam's two launches.
+struct AdamArgs {
+    float* w[3]; float* m[3]; float* v[3];
+    float* step[3]; unsigned int* ticket;
+    int64_t end0, end1, P;             // parameter k lives in tensor 0 if k < end0, 1 if k < end1, else 2
+    double lr, b1, b2; float eps;
+};
+
+__global__ __launch_bounds__(256) void k_mix_adam(const float* __restrict__ flat, const float* __restrict__ reg_dev, float reg_host, float eps, AdamArgs a,
+                                                 float* __restrict__ losses, float* __restrict__ loss_accum, int32_t* __restrict__ step_counter) {
+    __shared__ float sc[2];
+    const int64_t P = a.P;
+    // every workgroup reads the step count BEFORE the last one to finish (ticket below) writes the incremented value
+    const float t = a.step[0][0] + 1.0f;
+    if (threadIdx.x == 0) {
+        sc[0] = (float)(a.lr / (1.0 - pow(a.b1, (double)t)));
+        sc[1] = (float)sqrt(1.0 - pow(a.b2, (double)t));
+    }
+    __syncthreads();
+    const float reg = reg_dev ? reg_dev[0] : reg_host;
+    const float ih = 1.0f / (flat[2 * P + 2] + eps), it = 1.0f / (flat[2 * P + 3] + eps);
+    const float wt = reg * it;
+    const float step_size = sc[0], c2s = sc[1];
+    const float w1 = (float)(1.0 - a.b1), b2 = (float)a.b2, w2 = (float)(1.0 - a.b2);
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < P; k += (int64_t)gridDim.x * 256) {
+        const float g = flat[k] * ih + flat[P + k] * wt;
+        const int which = k < a.end0 ? 0 : (k < a.end1 ? 1 : 2);
+        const int64_t j = k - (which == 0 ? 0 : (which == 1 ? a.end0 : a.end1));
+        float m = a.m[which][j], v = a.v[which][j];
+        m = m + w1 * (g - m);
+        v = b2 * v + w2 * g * g;
+        a.m[which][j] = m;
+        a.v[which][j] = v;
+        a.w[which][j] -= step_size * m / (sqrtf(v) / c2s + a.eps);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {   // all workgroups have read the old step count
+            a.step[0][0] = t; a.step[1][0] = t; a.step[2][0] = t;
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float h = flat[2 * P] * ih, tl = flat[2 * P + 1] * it;
+            if (losses) { losses[0] = h + reg * tl; losses[1] = h; losses[2] = tl; }
+            if (loss_accum) { loss_accum[0] += h + reg * tl; loss_accum[1] += h; loss_accum[2] += tl; }
+            if (step_counter) step_counter[0] += 1;
+        }
+    }
+}
+
+extern "C" int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
+                                 float* loss_accum, int32_t* step_counter, void* stream) {
+    if (!flat || !adam) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL buffer");
+    AdamArgs a{};
+    int64_t P = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (!adam->param[i] || !adam->exp_avg[i] || !adam->exp_avg_sq[i] || adam->numel[i] <= 0)
+            return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: parameter tensor %d: NULL pointer or non-positive size", i);
+        if (!adam->step[i]) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL step count of tensor %d", i);
+        a.w[i] = adam->param[i]; a.m[i] = adam->exp_avg[i]; a.v[i] = adam->exp_avg_sq[i]; a.step[i] = adam->step[i];
+        P += adam->numel[i];
+    }
+    if (!adam->ticket) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL ticket");
+    if (!(adam->lr > 0) || !(adam->beta1 >= 0 && adam->beta1 < 1) || !(adam->beta2 >= 0 && adam->beta2 < 1) || !(adam->eps >= 0))
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: bad hyper-parameters");
+    a.ticket = adam->ticket;
+    a.end0 = adam->numel[0]; a.end1 = adam->numel[0] + adam->numel[1]; a.P = P;
+    a.lr = adam->lr; a.b1 = adam->beta1; a.b2 = adam->beta2; a.eps = (float)adam->eps;
+    const int grid = (int)((P + 255) / 256 < 512 ? (P + 255) / 256 : 512);
+    hipLaunchKernelGGL(k_mix_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, flat, reg_dev, (float)reg, (float)eps, a, losses, loss_accum, step_counter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_mix_adam_f32: %s", hipGetErrorString(e));
+    return HJBX_OK;
+}

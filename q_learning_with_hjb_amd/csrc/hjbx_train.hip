@@ -543,31 +543,6 @@ __global__ __launch_bounds__(256) void k_train_reduce(const float* __restrict__ 
     }
 }
 
-// ---- kernel 4: divide by the counts and mix (vhjb.py:241, 253, 284) ----------------------------------------------------------------
-// mixed = g_h / (#interior + eps) + reg g_t / (#done + eps); losses = {hjb + reg termination, hjb, termination}.  One launch instead of the
-// dozen element-wise launches the same arithmetic costs in torch (at a minibatch of 256 the whole step is launch bound).
-__global__ __launch_bounds__(256) void k_mix_gradients(const float* __restrict__ flat, int64_t P, const float* __restrict__ reg_dev, float reg_host,
-                                                      float eps, float* __restrict__ mixed, float* __restrict__ losses) {
-    const float reg = reg_dev ? reg_dev[0] : reg_host;
-    const float ih = 1.0f / (flat[2 * P + 2] + eps), it = 1.0f / (flat[2 * P + 3] + eps);
-    const float wt = reg * it;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < P; k += (int64_t)gridDim.x * 256) mixed[k] = flat[k] * ih + flat[P + k] * wt;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && losses) {
-        const float h = flat[2 * P] * ih, t = flat[2 * P + 1] * it;
-        losses[0] = h + reg * t; losses[1] = h; losses[2] = t;
-    }
-}
-
-extern "C" int hjbx_mix_gradients_f32(const float* flat, int64_t n_params, const float* reg_dev, double reg, double eps, float* mixed, float* losses,
-                                      void* stream) {
-    if (!flat || !mixed || n_params <= 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_gradients_f32: NULL buffer or non-positive parameter count");
-    const int grid = (int)((n_params + 255) / 256 < 512 ? (n_params + 255) / 256 : 512);
-    hipLaunchKernelGGL(k_mix_gradients, dim3(grid), dim3(256), 0, (hipStream_t)stream, flat, n_params, reg_dev, (float)reg, (float)eps, mixed, losses);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_mix_gradients_f32: %s", hipGetErrorString(e));
-    return HJBX_OK;
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 static int device_cus() { return hjbx_device_cus(); }   // per device ordinal (hjbx_host.hpp)
 

@@ -176,7 +176,7 @@ __device__ __forceinline__ void coop_outer(f32x16 (&acch)[NB], LPc Ah, LPc Bh, f
 #define COOP_SYNC() __syncthreads()
 #endif
 
-template <int MODE, int ACT, typename S>
+template <int MODE, int ACT, int PS, typename S>
 __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, TaskP<float, S::N, S::M> tk_k, Limits<float, S::M> lim_k,
                                                        const float* __restrict__ W1g, const float* __restrict__ W2g, const float* __restrict__ W3g,
                                                        const float* __restrict__ x, const float* __restrict__ cost, const float* __restrict__ done,
@@ -208,6 +208,20 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int ob = w & 1, kh = w >> 1;                 // y = W3'h2: output block and contraction half of this wave
+    // Small batches (PS = 4: at most a quarter as many tiles as CUs): FOUR workgroups work on the same tile -- each runs the tile's chains
+    // (redundantly: that costs no time) but accumulates only column block `part` of the outer products (dW2: one of four; dW3: parts 0, 1
+    // one of two each), dW1 and the loss sums going to part 0: a tile's 288 outer-product MFMAs per wave shrink to 48-96 on the latency
+    // path of the reference's minibatch of 256 (8 tiles -> 32 CUs).  PS is a template parameter: a run-time choice of the owned blocks
+    // inside the MFMA loops cost 60-110 spilled registers.
+    static_assert(PS == 1 || PS == 4, "");
+    constexpr int psplit = PS;
+    constexpr int NB2 = PS == 4 ? 1 : 4, NB3 = PS == 4 ? 1 : 2;
+    const int part = PS == 4 ? (int)(blockIdx.x & 3u) : 0;
+    const int col2 = PS == 4 ? 32 * part * kExLd : 0;          // offset of this part's column block inside a 128-row image (dW2)
+    const int col3 = PS == 4 ? 32 * (part & 1) * kExLd : 0;    //                                            64-row image (dW3)
+    const bool do3 = PS == 1 || part < 2;
+    const bool own1 = part == 0;                               // dW1 and the loss sums
+    const float m1 = own1 ? 1.0f : 0.0f;                       // (dW1 of the other parts accumulates zeros: a factor, not a branch inside the MFMA loops)
     // LDS byte addresses (the low 32 bits of a flat pointer into the LDS aperture are the LDS byte address)
     auto lds = [](const void* q) { return (uint32_t)(uintptr_t)q; };
     auto lds3 = [](LPc q) { return lds_addr(q); };
@@ -226,11 +240,11 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     const int exO = i * kExLd + h;                     //                 B operand of column block j = image[32 j + i][2 s + h]
     constexpr int AO1 = 2 * kLD2 * 4, AO3 = 2 * kLD3 * 4, BOX = 2 * kExLd * 4;
 
-    f32x16 acc2h[4], acc2t[4], acc3h[2], acc3t[2];     // dW2 row block w (hjb, termination), dW3 row block w: accumulators of the whole launch
+    f32x16 acc2h[NB2], acc2t[NB2], acc3h[NB3], acc3t[NB3];   // dW2 row block w (hjb, termination), dW3 row block w: accumulators of the whole launch
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { zero16(acc2h[j]); zero16(acc2t[j]); }
+    for (int j = 0; j < NB2; ++j) { zero16(acc2h[j]); zero16(acc2t[j]); }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { zero16(acc3h[j]); zero16(acc3t[j]); }
+    for (int j = 0; j < NB3; ++j) { zero16(acc3h[j]); zero16(acc3t[j]); }
     f32x2 w1h[N / 2], w1t[N / 2];                      // dW1[k][f], f = tid & 127, over the samples 16 (tid >> 7) .. + 15 of every tile
 #pragma unroll                                         // (pairs of k: one v_pk_fma_f32 per two entries; N is even)
     for (int k = 0; k < N / 2; ++k) w1h[k] = w1t[k] = f32x2{0.f, 0.f};
@@ -249,8 +263,9 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         cstv = ok ? cost[env] : 1.f;
     };
     float xs_n[N], dn_n, cst_n;
-    fetch(blockIdx.x, xs_n, dn_n, cst_n);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tile_stride = gridDim.x / (unsigned)psplit;
+    fetch(blockIdx.x / (unsigned)psplit, xs_n, dn_n, cst_n);
+    for (int64_t tile = blockIdx.x / (unsigned)psplit; tile < ntiles; tile += tile_stride) {
         asm volatile("" ::: "memory");   // the weights are loop invariant: keep their LDS reads inside the loop (see hjbx_mlp.hip)
         LP E0 = E0g, E1 = E1g, E2 = E2g, rsp = rsg, zsp = zsg, gzbsp = gzbsg;
         asm volatile("" : "+v"(E0), "+v"(E1), "+v"(E2), "+v"(rsp), "+v"(zsp), "+v"(gzbsp));   // (see LP above)
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #if !defined(HJBX_COOP_NO_W1) && !defined(HJBX_COOP_NO_FILL2)
                 if constexpr (st % 4 == 0) {
                     constexpr int s2 = st / 4;
-                    const float a = a1p[s2];
+                    const float a = a1p[s2] * m1;
                     const f32x2 a2v{a, a};
 #pragma unroll
                     for (int k4 = 0; k4 < NP / 4; ++k4) {
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         if (!valid) lt = rterm = 0.f;
         if (w == 0 && h == 0) {
             L.rs[i] = rterm;
-            if (valid) { L.sums[1][i] += (double)lt; L.sums[2][i] += 1.0 - (double)dn; L.sums[3][i] += (double)dn; }
+            if (valid && own1) { L.sums[1][i] += (double)lt; L.sums[2][i] += 1.0 - (double)dn; L.sums[3][i] += (double)dn; }
         }
         // ---- 4. d2 = (W3 dy).s2 -------------------------------------------------------------------------------------------------------
         zero16(acc);
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int k = 0; k < N; ++k) gzb[k] = q[k] * p.istd[k];
         if (w == 0 && h == 0) {
-            if (valid) L.sums[0][i] += (double)li;
+            if (valid && own1) L.sums[0][i] += (double)li;
 #pragma unroll
             for (int k = 0; k < N; ++k) { L.zs[i * NP + k] = z[k]; L.gzbs[i * NP + k] = gzb[k]; }
         }
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         const LP4 gz4 = (LP4)(gzbsp + sW1 * NP), zz4 = (LP4)(zsp + sW1 * NP);
         auto w1_part1 = [&](int s2) __attribute__((always_inline)) {
 #if !defined(HJBX_COOP_NO_W1) && !defined(HJBX_COOP_NO_FILL1)
-            const float d = d1p[s2];
+            const float d = d1p[s2] * m1;
             const float rd = rp1[s2] * d;
             const f32x2 d2v{d, d}, rd2v{rd, rd};
 #pragma unroll
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) w1_part1(s2);
 #endif
-        COOP_OUTER(coop_outer<4, true, false>(acc2h, E0, E1, acc2t, E0, E1, rsp, exA, exO, h, w1_part1);)
+        COOP_OUTER(coop_outer<NB2, true, false>(acc2h, E0, E1 + col2, acc2t, E0, E1 + col2, rsp, exA, exO, h, w1_part1);)
         // ---- 7. t2 = W2'dh1b, dh2b = t2.s2 -------------------------------------------------------------------------------------------------
         zero16(acc);
         COOP_CHAIN(coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));)
@@ -456,10 +471,10 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         ex_write(E1 + exW, dh2b);
         if (kh == 0) ex_write(E2 + exWy, dyr);
         COOP_SYNC();                                                                    // (K) E1 = dh2b, E2[0:64] = dy
-        COOP_OUTER(coop_outer<2, true, false>(acc3h, E1, E2, acc3t, E1, E2, rsp, exA, exO, h);)    // dW3 += dh2b (x) dy
+        COOP_OUTER(coop_outer<NB3, true, false>(acc3h, E1, E2 + col3, acc3t, E1, E2 + col3, rsp, exA, exO, h);)   // (PS = 4: parts 2, 3 compute it too and discard it: no run-time branch here)    // dW3 += dh2b (x) dy
         // the next tile's inputs: issued here, not at the top of the tile -- their N + 2 registers would be live through the phases with the
         // highest register pressure (steps 4-7), and three phases (~3 us) still cover the HBM latency
-        fetch(tile + gridDim.x, xs_n, dn_n, cst_n);
+        fetch(tile + tile_stride, xs_n, dn_n, cst_n);
         // ---- 8. yb = 2 W3'dh2b (halves summed through E0) ------------------------------------------------------------------------------------
         zero16(acc);
         COOP_CHAIN(coop_chain<AO3, BOX, 32>(acc, aW3f, lds3(E1 + 64 * kh * kExLd + exB));)
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         }
         ex_write(E1 + exW, h2r);                                                            // (dh2b's readers, the outer products and chain 8, are past (L))
         COOP_SYNC();                                                                    // (M) E0[0:64] = yb, E1 = h2, E2[0:64] = dy
-        COOP_OUTER(coop_outer<2, true, true>(acc3h, E1, E0, acc3t, E1, E2, rsp, exA, exO, h);)              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
+        COOP_OUTER(coop_outer<NB3, true, true>(acc3h, E1, E0 + col3, acc3t, E1, E2 + col3, rsp, exA, exO, h);)              // dW3 += h2 (x) yb;  dW3_t += h2 (x) (r dy)
         // ---- 9. a2b = (W3 yb).s2 [+ c2] ------------------------------------------------------------------------------------------------------
         zero16(acc);
         COOP_CHAIN(coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));)
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         ex_write(E1 + exW, h1r);
         ex_write(E0 + exW, d2r);                                                            // (yb's readers, chain 9 and the outer products, finished before (N))
         COOP_SYNC();                                                                    // (O) E2 = a2b, E1 = h1, E0 = d2
-        COOP_OUTER(coop_outer<4, true, true>(acc2h, E1, E2, acc2t, E1, E0, rsp, exA, exO, h);)     // dW2 += h1 (x) a2b;  dW2_t += h1 (x) (r d2)
+        COOP_OUTER(coop_outer<NB2, true, true>(acc2h, E1, E2 + col2, acc2t, E1, E0 + col2, rsp, exA, exO, h);)     // dW2 += h1 (x) a2b;  dW2_t += h1 (x) (r d2)
         // ---- 10. a1b = (W2 a2b).s1 [+ c1]; dW1 second part ----------------------------------------------------------------------------------
         zero16(acc);
         COOP_CHAIN(coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E2 + exB));)
@@ -510,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #ifndef HJBX_COOP_NO_W1
 #pragma unroll 4
         for (int s2 = 0; s2 < 16; ++s2) {
-            const float a = a1p[s2];
+            const float a = a1p[s2] * m1;
             const f32x2 a2v{a, a};
 #pragma unroll
             for (int k4 = 0; k4 < NP / 4; ++k4) {
@@ -528,10 +543,23 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[blk * 1024 + r * 64 + lane] = a[r];
     };
+    if constexpr (PS == 4) {   // this part's column block; the other blocks of this workgroup's record are zero
+        f32x16 zero;
+        zero16(zero);
+        for (int j = 0; j < 4; ++j) {
+            put(w * 4 + j, j == part ? acc2h[0] : zero);
+            put(kCoopSet + w * 4 + j, j == part ? acc2t[0] : zero);
+        }
+        for (int j = 0; j < 2; ++j) {
+            put(16 + w * 2 + j, (do3 && j == (part & 1)) ? acc3h[0] : zero);
+            put(kCoopSet + 16 + w * 2 + j, (do3 && j == (part & 1)) ? acc3t[0] : zero);
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { put(w * 4 + j, acc2h[j]); put(kCoopSet + w * 4 + j, acc2t[j]); }
+        for (int j = 0; j < NB2; ++j) { put(w * 4 + j, acc2h[j]); put(kCoopSet + w * 4 + j, acc2t[j]); }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { put(16 + w * 2 + j, acc3h[j]); put(kCoopSet + 16 + w * 2 + j, acc3t[j]); }
+        for (int j = 0; j < NB3; ++j) { put(16 + w * 2 + j, acc3h[j]); put(kCoopSet + 16 + w * 2 + j, acc3t[j]); }
+    }
     float* o1 = partial_w1 + ((int64_t)blockIdx.x * 2 + (tid >> 7)) * (2 * N * 128);
 #pragma unroll
     for (int k = 0; k < N; ++k) { o1[k * 128 + fW1] = w1h[k >> 1][k & 1]; o1[(N + k) * 128 + fW1] = w1t[k >> 1][k & 1]; }
@@ -593,13 +621,14 @@ __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restri
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
-struct CoopWs { size_t partial, partial_w1, sums, total; int grid; };
+struct CoopWs { size_t partial, partial_w1, sums, total; int grid, psplit; };
 static CoopWs coop_ws(int64_t B, int n) {
     CoopWs w{};
     int n_cu = hjbx_device_cus();
     if (n_cu <= 0) n_cu = 256;
     const int64_t ntiles = (B + 31) / 32;
-    w.grid = (int)(ntiles < n_cu ? ntiles : n_cu);
+    w.psplit = 4 * ntiles <= n_cu ? 4 : 1;                             // workgroups per tile (small batches: see k_train_coop)
+    w.grid = (int)(ntiles * w.psplit < n_cu ? ntiles * w.psplit : n_cu);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     w.partial = up((size_t)w.grid * kCoopBlocks * 1024 * sizeof(float));
     w.partial_w1 = up((size_t)w.grid * 2 * 2 * n * 128 * sizeof(float));
@@ -631,8 +660,12 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
         const float *W1 = (const float*)mlp->W1, *W2 = (const float*)mlp->W2, *W3 = (const float*)mlp->W3;
         hipStream_t s = (hipStream_t)st;
         auto go = [&](auto mode_c, auto act_c) {
-            hipLaunchKernelGGL((k_train_coop<decltype(mode_c)::value, decltype(act_c)::value, S>), dim3(w.grid), dim3(256), 0, s, sys, p, tk, lim, W1, W2, W3, x,
-                               cost, done, (float)task->eps, partial, partial_w1, sums, B, ntiles);
+            if (w.psplit == 4)
+                hipLaunchKernelGGL((k_train_coop<decltype(mode_c)::value, decltype(act_c)::value, 4, S>), dim3(w.grid), dim3(256), 0, s, sys, p, tk, lim, W1, W2, W3,
+                                   x, cost, done, (float)task->eps, partial, partial_w1, sums, B, ntiles);
+            else
+                hipLaunchKernelGGL((k_train_coop<decltype(mode_c)::value, decltype(act_c)::value, 1, S>), dim3(w.grid), dim3(256), 0, s, sys, p, tk, lim, W1, W2, W3,
+                                   x, cost, done, (float)task->eps, partial, partial_w1, sums, B, ntiles);
         };
         const bool tanh_net = mlp->activation == HJBX_ACT_TANH;
         if (mode == HJBX_RESIDUAL_NORMALISED) {

@@ -140,6 +140,19 @@ def test_value_loss_grad_properties_at_scale(impl):
     assert float((only_live[:P].double() - full[:P].double()).abs().max()) <= 2e-5 * float(scale[0])
 
 
+def _mixed_grads(ctl, xs, dones, costs, reg):
+    """The gradient the fused update applies: its Adam step rides in the mix kernel (hjbx_mix_adam_f32) and the mixed gradient is never
+    materialised, so the tests take it from the same flat buffer beforehand."""
+    assert ctl._native_adam
+    params = list(ctl.value_function_approximator.parameters())
+    mixed, _ = _ops.mix_gradients(ctl.value_loss_gradient(xs, dones, costs), sum(p.numel() for p in params), reg, ctl.epsilon)
+    grads, off = [], 0
+    for p in params:
+        grads.append(mixed[off:off + p.numel()].view_as(p).clone())
+        off += p.numel()
+    return grads
+
+
 def test_fused_and_autograd_updates_agree():
     """params_update through the fused kernels == params_update through PyTorch autograd (same float32 data): losses to 1e-5, the
     first Adam step's parameter change to 1e-3 of the step size except where |g| ~ Adam's eps."""
@@ -148,10 +161,14 @@ def test_fused_and_autograd_updates_agree():
         d, ctl = controller("cartpole", fused_param_grad=fused, graph_updates=False)
         assert ctl.fused_param_grad == fused
         xs, dones, costs = _batch(d, ctl, 256, 3)
-        before = [p.detach().clone() for p in ctl.value_function_approximator.parameters()]
+        params = list(ctl.value_function_approximator.parameters())
+        before = [p.detach().clone() for p in params]
+        if fused:
+            grads = _mixed_grads(ctl, xs, dones, costs, 0.37)
         tot, h, t = ctl.params_update(xs, dones, costs, 0.37)
-        res[fused] = (float(tot), float(h), float(t), [(p.detach() - b) for p, b in zip(ctl.value_function_approximator.parameters(), before)],
-                      [p.grad.detach().clone() for p in ctl.value_function_approximator.parameters()])
+        if not fused:
+            grads = [p.grad.detach().clone() for p in params]
+        res[fused] = (float(tot), float(h), float(t), [(p.detach() - b) for p, b in zip(params, before)], grads)
     a, b = res[True], res[False]
     for k in range(3):
         assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-7
@@ -205,8 +222,9 @@ def test_tanh_updates_through_the_fused_kernels_match_autograd():
         d, ctl = controller("cartpole", activation="tanh", fused_param_grad=fused, graph_updates=False, residual_mode=_abi.RESIDUAL_RAW)
         assert ctl.fused_param_grad == fused
         xs, dones, costs = _batch(d, ctl, 256, 3)
+        grads = _mixed_grads(ctl, xs, dones, costs, 0.37) if fused else None
         tot, h, t = ctl.params_update(xs, dones, costs, 0.37)
-        res[fused] = (float(tot), float(h), float(t), [p.grad.detach().clone() for p in ctl.value_function_approximator.parameters()])
+        res[fused] = (float(tot), float(h), float(t), grads or [p.grad.detach().clone() for p in ctl.value_function_approximator.parameters()])
     a, b = res[True], res[False]
     for k in range(3):
         assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-7
@@ -252,3 +270,39 @@ def test_mix_gradients_kernel_vs_formula():
         assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
         assert abs(float(losses[1]) - float(wh)) < 1e-6 * abs(float(wh)) and abs(float(losses[2]) - float(wt)) < 1e-6 * abs(float(wt))
         assert abs(float(losses[0]) - float(wh + 0.37 * wt)) < 1e-6 * abs(float(wh + 0.37 * wt))
+
+
+def test_mix_adam_follows_torch_adam_step_for_step():
+    """hjbx_mix_adam_f32 = hjbx_mix_gradients_f32 + optax.adam (vhjb.py:120, 262-263) in one launch: against torch.optim.Adam on the mixed
+    gradient of the same flat buffers, ten steps from a non-trivial state; moments to float32 rounding, weights to a few ulp of the step."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(4, 128), (128, 128), (128, 64)]
+    P = sum(a * b for a, b in shapes)
+    ours = [torch.randn(sh, generator=g, device="cuda") * 0.1 for sh in shapes]
+    theirs = [torch.nn.Parameter(w.clone()) for w in ours]
+    lr, b1, b2, eps_adam, eps = 3e-3, 0.9, 0.999, 1e-8, 1e-7
+    opt = torch.optim.Adam(theirs, lr=lr, betas=(b1, b2), eps=eps_adam)
+    m = [torch.zeros_like(w) for w in ours]
+    v = [torch.zeros_like(w) for w in ours]
+    steps = [torch.zeros((), device="cuda") for _ in ours]
+    ticket = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    acc, counter = torch.zeros(3, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    want_acc = torch.zeros(3, device="cuda")
+    for it in range(10):
+        flat = torch.randn((2 * P + 4,), generator=g, device="cuda") * (10.0 ** (it % 3 - 1))
+        flat[2 * P + 2], flat[2 * P + 3] = 200.0 + it, 56.0 - it
+        reg = 0.01 * (it + 1)
+        mixed, losses = _ops.mix_gradients(flat, P, reg, eps)
+        off = 0
+        for p in theirs:
+            p.grad = mixed[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        opt.step()
+        got = _ops.mix_adam(flat, reg, eps, ours, m, v, steps, ticket, lr, b1, b2, eps_adam, loss_accum=acc, step_counter=counter)
+        want_acc += losses
+        assert torch.equal(got, losses) and int(ticket) == 0 and all(float(k) == it + 1 for k in steps)
+        for w, p, mm, vv in zip(ours, theirs, m, v):
+            st = opt.state[p]
+            assert torch.allclose(mm, st["exp_avg"], rtol=1e-5, atol=1e-9) and torch.allclose(vv, st["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+            assert (w - p).abs().max().item() <= 2e-6 * lr * (it + 1) + 1e-7 * p.abs().max().item()
+    assert int(counter) == 10 and torch.allclose(acc, want_acc, rtol=1e-6)

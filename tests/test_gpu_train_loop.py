@@ -129,3 +129,56 @@ def test_sgdr_schedule_follows_the_update_counter():
     vals = [ctl.regularization_scheduler(k) for k in (0, 500, 1000, 1500, 2000, 2001, 19999, 20000, 50000)]
     assert vals[0] == 0.0 and abs(vals[1] - 0.5e-5) < 1e-18 and abs(vals[2] - 1e-5) < 1e-18 and abs(vals[3] - 0.5e-5) < 1e-12
     assert vals[4] == 0.0 and 0 < vals[5] < 2e-8 and vals[7] == 0.0 and vals[8] == 0.0
+
+
+@pytest.mark.parametrize("name,activation,batch", [("cartpole", "relu", 64), ("quad2d", "tanh", 16)])
+def test_device_driven_fit_phase_equals_the_per_minibatch_loop(name, activation, batch):
+    """The fit phase replayed from ONE hipGraph per update with the minibatch selection, the regularisation weight and the loss sums kept
+    on the device (VHJBController._fit_epoch_graphed: hjbx_replay_gather_f32 + hjbx_mix_gradients_f32's accumulators) against the plain
+    loop `for minibatch: params_update(...)` (vhjb.py:314-324) on eager launches: same seeds -> same permutations -> the same kernels on
+    the same inputs, so weights, Adam state, counters and the returned loss lists agree to rounding of the float32 loss accumulation."""
+    kw = dict(epochs=3, num_of_trajectories_per_epoch=5, maximum_step=40, batch_size=batch, maximum_buffer_size=700,
+              regularization_warmup_steps_per_cycle=4, regularization_total_steps_per_cycle=9, regularization_num_of_cycles=2, regularization_peak_value=1e-2)
+    outs, ctls = [], []
+    for graphed in (True, False):
+        d = make_dynamics(name)
+        ctl = VHJBController(d, make_vhjb_config(name, **kw), dtype=torch.float32, graph_updates=graphed, activation=activation)
+        assert ctl.fused_param_grad and ctl._fit_graph_usable() == graphed
+        outs.append(ctl.train())
+        ctls.append(ctl)
+    a, b = ctls
+    assert a._fit_graph is not None and a._graphed_update is None and b._fit_graph is None      # the device-driven path did run
+    assert a.update_counter == b.update_counter > 3 and a.regularization == b.regularization
+    assert len(a.replay_buffer) == len(b.replay_buffer)
+    for wa, wb in zip(a.value_function_approximator.weights, b.value_function_approximator.weights):
+        assert torch.equal(wa, wb)
+    for pa, pb in zip(a.value_function_approximator.parameters(), b.value_function_approximator.parameters()):
+        sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
+    for la, lb in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(la, lb, rtol=2e-6)
+
+
+def test_replay_gather_reads_its_minibatch_number_from_the_device():
+    from q_learning_with_hjb_amd import _ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cap, n, batch = 1000, 6, 96
+    bx = torch.randn((cap, n), generator=g, device="cuda")
+    bc, bd = torch.randn((cap,), generator=g, device="cuda"), (torch.rand((cap,), generator=g, device="cuda") < 0.3).float()
+    perm = torch.randperm(cap, generator=g, device="cuda").to(torch.int32)
+    table = torch.arange(10, device="cuda", dtype=torch.float32) * 0.5
+    xs, cs, ds = torch.empty((batch, n), device="cuda"), torch.empty((batch,), device="cuda"), torch.empty((batch,), device="cuda")
+    reg = torch.zeros((), device="cuda")
+    for k in (0, 3, 9):
+        step = torch.tensor([k], dtype=torch.int32, device="cuda")
+        _ops.replay_gather(bx, bc, bd, perm, step, table, xs, cs, ds, reg)
+        idx = perm[k * batch:(k + 1) * batch].long()
+        assert torch.equal(xs, bx[idx]) and torch.equal(cs, bc[idx]) and torch.equal(ds, bd[idx]) and float(reg) == 0.5 * k
+    # the accumulators of the mix kernel: losses added, counter advanced
+    P = 50
+    flat = torch.rand((2 * P + 4,), generator=g, device="cuda") + 1
+    acc, step = torch.tensor([1.0, 2.0, 3.0], device="cuda"), torch.tensor([7], dtype=torch.int32, device="cuda")
+    mixed, losses = _ops.mix_gradients(flat, P, 0.25, 1e-7, loss_accum=acc, step_counter=step)
+    mixed0, losses0 = _ops.mix_gradients(flat, P, 0.25, 1e-7)
+    assert torch.equal(mixed, mixed0) and torch.equal(losses, losses0) and int(step) == 8
+    assert torch.allclose(acc, torch.tensor([1.0, 2.0, 3.0], device="cuda") + losses0, rtol=1e-7)

@@ -298,7 +298,7 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
         text = asm.read_text()
         assert text.count(mfma) >= 30 * per
         kernels = meta.findall(text)
-        assert len(kernels) == 30 and sum("k_vhjb_rollout_mfma" in k[0] for k in kernels) == 24 and sum("k_value_grad_mfma" in k[0] for k in kernels) == 6
+        assert len(kernels) == 30 and sum("k_vhjb_rollout_mfma" in k[0] for k in kernels) == 23 and sum("k_value_grad_mfma" in k[0] for k in kernels) == 7
         for name, private, _sgpr_spill, vgpr_spill in kernels:
             assert int(private) == 0 and int(vgpr_spill) == 0, f"{name}: {private} bytes of scratch, {vgpr_spill} spilled VGPRs"
         if asm in (outs[2], outs[3]):
@@ -314,10 +314,10 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     # and NO scratch (its first build hoisted ~200 loop-invariant LDS addresses out of the tile loop and spilled 78 of them)
     text = coop_asm.read_text()
     kernels = [k for k in meta.findall(text) if "k_train_coop" in k[0] and "reduce" not in k[0]]
-    assert len(kernels) == 9 * 4, len(kernels)                 # 9 system instantiations x 2 residual modes x 2 activations
+    assert len(kernels) == 9 * 4 * 2, len(kernels)             # 9 system instantiations x 2 residual modes x 2 activations x 2 tile splits (PS = 1, 4)
     for name, private, _sgpr_spill, vgpr_spill in kernels:
         assert int(private) == 0 and int(vgpr_spill) == 0, f"{name}: {private} bytes of scratch, {vgpr_spill} spilled VGPRs"
-    assert text.count("v_mfma_f32_32x32x2_f32") >= 36 * 690
+    assert text.count("v_mfma_f32_32x32x2_f32") >= 36 * 690 + 36 * 400
 
 
 def test_graft_entry_build_check_passes():

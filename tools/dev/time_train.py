@@ -28,4 +28,4 @@ for label, kern, arith in (("coop/f32", 0, 0), ("pair/f32", 1, 0), ("pair/f16x2"
     _abi.set_option(_abi.OPT_TRAIN_KERNEL, kern)
     _abi.set_option(_abi.OPT_MLP_ARITHMETIC, arith)
     r = bench.optimiser_step(1, None)
-    print(label, "params_update 256", json.dumps({k: r[k] for k in ("ms_per_update", "updates_per_s", "gradient", "mode")}), flush=True)
+    print(label, "params_update 256", json.dumps({k: r[k] for k in ("ms_per_update", "updates_per_s", "gradient", "mode", "fit_phase")}), flush=True)
