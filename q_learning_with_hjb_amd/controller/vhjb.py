@@ -628,8 +628,10 @@ class VHJBController(Controller):
         if not (self._graphed_update is not None and xs is self._graphed_update.inputs[0]):
             xs, dones, costs = self._dev(xs), self._dev(dones), self._dev(costs)
         if self._reg_buf is None:
-            self._reg_buf = torch.zeros((), dtype=self.dtype, device=self.device)
-        self._reg_buf.fill_(float(regularization))
+            self._reg_buf, self._reg_val = torch.zeros((), dtype=self.dtype, device=self.device), 0.0
+        if float(regularization) != self._reg_val:          # (one launch saved whenever the weight did not move)
+            self._reg_buf.fill_(float(regularization))
+            self._reg_val = float(regularization)
         if self._graphed_update is None or not self._graphed_update.matches(xs, dones, costs, self._reg_buf):
             self._graphed_update = GraphedStep(self.optimizer, list(self.value_function_approximator.parameters()), self._update_core,
                                                (xs, dones, costs, self._reg_buf))

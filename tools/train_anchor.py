@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--warm_start", type=int, default=0, help="seed the replay buffer with this many closed loops of the model-based "
                     "controller first (BASELINE configs[2]: acrobot energy-shaping warm-start + vhjb)")
     ap.add_argument("--arithmetic", default=None, choices=["f32", "bf16x3", "f16x2"], help="value-network arithmetic of the fused kernels "
-                    "(HJBX_OPT_MLP_ARITHMETIC; default: the library's = f16x2)")
+                    "(HJBX_OPT_MLP_ARITHMETIC; default: the library's = f32)")
     args = ap.parse_args()
     if args.arithmetic:
         from q_learning_with_hjb_amd import _abi
@@ -63,7 +63,7 @@ def main():
             np.random.seed(123)
             cost_by_arithmetic[nm] = float(test_policy(pol, dyn, mb, T=args.T, batch=args.starts)["cost_learned"].sum(0).mean())
         _A.set_option(_A.OPT_MLP_ARITHMETIC, prev)
-    print(json.dumps(dict(env=args.env, seed=args.seed, arithmetic=args.arithmetic or "f16x2", activation=args.activation, notebook=args.notebook, epochs=args.epochs,
+    print(json.dumps(dict(env=args.env, seed=args.seed, arithmetic=args.arithmetic or "f32", activation=args.activation, fused_param_grad=bool(pol.fused_param_grad), device_driven_fit=bool(pol._fit_graph is not None), notebook=args.notebook, epochs=args.epochs,
                           warm_start=None if ws is None else dict(records=ws["records"], average_trajectory_cost=round(ws["average_trajectory_cost"], 2)), updates=pol.update_counter, train_seconds=round(train_s, 1),
                           replay_records=len(pol.replay_buffer), avg_traj_len_first=lists[2][0], avg_traj_len_last=lists[2][-1],
                           hjb_loss_first=lists[4][0] if lists[4] else None, hjb_loss_last=lists[4][-1] if lists[4] else None,
