@@ -120,7 +120,8 @@ def main():
     # ---- the cooperative parameter-gradient kernel (hjbx_train_coop.hip): HBM bytes per sample and matrix-pipe occupancy -------------
     train = {}
     for sysname_, nst in (("Cartpole", 4), ("NearHover", 10)):
-        K = f"k_train_coop<0, 0, hjbx::{sysname_}"
+        K = f"k_train_coop<0, 0, 1, hjbx::{sysname_}"             # <residual mode, activation, tile split, system>: split 1 = large batches
+        K4 = f"k_train_coop<0, 0, 4, hjbx::{sysname_}"            # split 4 = the reference's minibatch (four workgroups per tile)
         big = lambda r: int(r["Grid_Size"]) >= 256 * 256          # the B = 2^20 launches (256 workgroups of 256 threads)
         d = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -140,17 +141,18 @@ def main():
         if "GRBM_GUI_ACTIVE" in sq and "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
             cyc = sq["GRBM_GUI_ACTIVE"] / 8
             d.update(gpu_cycles_per_launch=cyc, mfma_pipe_busy_fraction=sq["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, counters=sq)
-        tr_ = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows(f"{prof}/train/trace/*/*_kernel_trace.csv") if K in r["Kernel_Name"]]
+        trows = rows(f"{prof}/train/trace/*/*_kernel_trace.csv")
+        tr_ = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trows if K in r["Kernel_Name"] or K4 in r["Kernel_Name"]]
         if tr_:
             tr_.sort()
             nbig = [t for t in tr_ if t > 1_000_000]
-            nsmall = [t for t in tr_ if t <= 1_000_000]
+            nsmall = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trows if K4 in r["Kernel_Name"])
             if nbig:
                 d["rocprof_ms_B_2p20"] = nbig[len(nbig) // 2] / 1e6
                 d["samples_per_s_B_2p20"] = B / (nbig[len(nbig) // 2] * 1e-9)
             if nsmall:
                 d["rocprof_us_B_256"] = nsmall[len(nsmall) // 2] / 1e3
-        train[K + "<float>>"] = d
+        train[f"k_train_coop<0, 0, PS, hjbx::{sysname_}<float>>"] = d
     json.dump(train, open(f"{dst}/r03_train_coop_summary.json", "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in train.items()}, indent=1))
     st2 = rows(f"{prof}/train/trace/*/*_kernel_stats.csv")
