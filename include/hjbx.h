@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 107 /* major*100 + minor */
+#define HJBX_VERSION 108 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -114,7 +114,7 @@ typedef enum hjbx_option {
     HJBX_OPT_MLP_ARITHMETIC = 3            /* arithmetic of the ReLU value network inside hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 and of the eight
                                               128 / 64-wide products of hjbx_value_loss_grad_f32 (mode 1 runs those on the f32 MFMA) (THE ONE KNOB
                                               THAT CHANGES RESULTS, within float32 rounding; inputs, outputs, accumulation, layer 1 and everything
-                                              outside the network are float32 in every mode; tanh networks always run mode 0):
+                                              outside the network are float32 in every mode; tanh and sin networks always run mode 0):
                                               0 (DEFAULT) = float32 MFMA, bitwise an fmaf chain: the arithmetic of the reference's float32 network
                                                   (controller/vhjb.py:17-60);
                                               1 = OPT-IN bf16x3: every float32 operand split EXACTLY into three bfloat16 pieces, the six largest piece
@@ -132,7 +132,7 @@ typedef enum hjbx_option {
                                               mode 0 on the device. */,
     HJBX_OPT_TRAIN_KERNEL = 4              /* implementation of hjbx_value_loss_grad_f32 in the float32 arithmetic (results agree to float32 summation
                                               order): 0 (default) = the cooperative single kernel (no scratch in HBM, a tile's chains split over the four
-                                              waves of a workgroup, ReLU and tanh); 1 = the round-2 pair of kernels (chains + outer products through a
+                                              waves of a workgroup; ReLU, tanh, sin); 1 = the round-2 pair of kernels (chains + outer products through a
                                               5-KB-per-sample scratch; ReLU only) -- kept for A/B measurements and for the f16x2 arithmetic */
 } hjbx_option;
 
@@ -173,7 +173,7 @@ typedef struct hjbx_controller {
 typedef enum hjbx_activation {
     HJBX_ACT_RELU = 0, /* controller/vhjb.py:52,56 and examples/drone_hovering.ipynb, 10D_quadcopte.ipynb */
     HJBX_ACT_TANH = 1, /* examples/cartpole_balancing.ipynb cell 6 */
-    HJBX_ACT_SIN = 2   /* examples/double_integrator_optimal_time.ipynb cell 5 (no fused kernel: HJBX_EUNSUPPORTED) */
+    HJBX_ACT_SIN = 2   /* examples/double_integrator_optimal_time.ipynb cell 5 (sin and cos evaluated to ~1e-7 absolute, branch-free) */
 } hjbx_activation;
 
 /* Value network of controller/vhjb.py:17-60 (no bias, BatchNorm off): device weight pointers,
@@ -333,7 +333,7 @@ int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const h
  * i.e. the gradients of the loss SUMS (the caller divides by the counts, vhjb.py:241, 253, and mixes with the regularisation weight,
  * :284) -- the buffer a data-parallel step all-reduces once.  hjb_loss is a function of dV/dx, so its gradient is a second-order
  * reverse sweep; both are evaluated in closed form (no autograd graph).  `mode` = hjbx_residual_mode.  Deterministic: no float atomics,
- * fixed summation order (the order depends on B and the device's CU count only).  ReLU and tanh networks with features [128,128,64]
+ * fixed summation order (the order depends on B and the device's CU count only).  ReLU, tanh and (state dimension <= 4) sin networks with features [128,128,64]
  * (HJBX_EUNSUPPORTED otherwise: the PyTorch autograd path remains).  workspace: hjbx_value_loss_grad_workspace_bytes(B) bytes (it depends on
  * HJBX_OPT_MLP_ARITHMETIC / HJBX_OPT_TRAIN_KERNEL: ask again after changing them), 256-byte aligned, need not be initialised. */
 size_t hjbx_value_loss_grad_workspace_bytes(int64_t B);

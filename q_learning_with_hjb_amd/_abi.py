@@ -37,6 +37,7 @@ _UNITS = (("hjbx_kernels.hip", (), "hjbx_kernels.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=1",), "hjbx_mlp_tanh.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=2",), "hjbx_mlp_x3.o"),
           ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=3", "-fno-slp-vectorize"), "hjbx_mlp_h2.o"),
+          ("hjbx_mlp.hip", ("-DHJBX_MLP_ACT=4",), "hjbx_mlp_sin.o"),
           ("hjbx_train.hip", ("-fno-slp-vectorize",), "hjbx_train.o"),
           ("hjbx_train_coop.hip", ("-fno-slp-vectorize",), "hjbx_train_coop.o"),
           ("hjbx_fit.hip", (), "hjbx_fit.o"),

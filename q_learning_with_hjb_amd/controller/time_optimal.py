@@ -39,7 +39,7 @@ class TimeOptimalVHJBController(Controller):
     examples/double_integrator_optimal_time.ipynb (cells 5, 7, 9, 11), batched on the device.
 
     * value net: `PDValueApproximator` of cell 5 = the VHJB network V = |MLP(x)|^2 + 1e-3 |x|^2 with `sin` activations
-      (`activation="relu"` gives the stock vhjb.py network and with it the fused MFMA rollout kernel);
+      (`activation="relu"` gives the stock vhjb.py network; all three activations run on the fused MFMA kernels);
     * control law u = -sign(gradV @ B) (cells 9, 11) generalised to a box: `hjbx_task.law = HJBX_LAW_BANGBANG`;
     * data: `num_states` points uniform in xf +- state_halfwidth, running cost 1 outside the target ball |e|^2 <= metric
       and 0 inside (cell 7) -- computed in the residual kernel, not stored;
@@ -71,7 +71,16 @@ class TimeOptimalVHJBController(Controller):
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, features, np.zeros(n), np.ones(n), self.xf, epsilon_scalar, dtype=self.dtype, device=self.device,
             generator=self._gen, activation=activation)
-        self.fused = activation in ("relu", "tanh") and self.dtype == torch.float32 and tuple(features) == (128, 128, 64)
+        builtin = dynamics.system.kind != _abi.SYS_USER
+        self.fused = (activation in ValueFunctionApproximator.FUSED_ACTIVATIONS and self.dtype == torch.float32 and tuple(features) == (128, 128, 64)
+                      and builtin)
+        # the parameter gradient of pd_hjb_loss through hjbx_value_loss_grad_f32 (RAW residual, done = 0) and the Adam step through
+        # hjbx_mix_adam_f32, like VHJBController (the sin network: state dimension <= 4); HJBX_FUSED_PARAM_GRAD=0 keeps PyTorch autograd
+        import os
+        self.fused_param_grad = (self.fused and (activation != "sin" or n <= 4) and self.device.type == "cuda"
+                                 and os.environ.get("HJBX_FUSED_PARAM_GRAD", "1") != "0")
+        self._adam_ticket = torch.zeros((1,), dtype=torch.int32, device=self.device) if self.fused_param_grad else None
+        self._ones = None
         self.graph_updates = self.device.type == "cuda"   # optimiser steps of `train` replay from a hipGraph
         self._graphed = None
         self.optimizer = torch.optim.Adam(self.value_function_approximator.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8,
@@ -152,6 +161,27 @@ class TimeOptimalVHJBController(Controller):
         return s / xs.shape[0]
 
     def params_update(self, xs):
+        import torch
+        if self.fused_param_grad:
+            # mean |gradV . xdot + running_cost| over the minibatch (cell 11) = sum / B: the flat buffer's hjb part divided by its count of
+            # interior samples (all of them: done = 0) -- hjbx_mix_adam_f32 with regularisation 0; its eps only guards 0 / 0 of the unused
+            # termination half
+            from .. import _ops
+            from .vhjb import adam_state
+            vf = self.value_function_approximator
+            params = list(vf.parameters())
+            B = xs.shape[0]
+            if self._zeros.shape[0] < B:
+                self._zeros = self._zeros.new_zeros(B)
+            z = self._zeros[:B]
+            if self._ones is None or self._ones.shape[0] < B:
+                self._ones = torch.ones(B, dtype=self.dtype, device=self.device)
+            # (costs = 1: the unused termination residual |V / (cost + eps) - 1| done must stay finite with this task's eps = 0)
+            flat = _ops.value_loss_grad(self.dynamics.system, self._task, vf.descriptor(), xs, self._ones[:B], z, _abi.RESIDUAL_RAW)
+            m, v, steps = adam_state(self.optimizer, params)
+            g = self.optimizer.param_groups[0]
+            losses = _ops.mix_adam(flat, 0.0, 1e-30, [p.data for p in params], m, v, steps, self._adam_ticket, g["lr"], g["betas"][0], g["betas"][1], g["eps"])
+            return losses[1]
         # differentiate w.r.t. fresh leaves aliasing the parameters (see VHJBController._update_core): a hipGraph capture of
         # this step must not meet grad accumulators that an older, still-alive autograd graph created on another stream
         params = list(self.value_function_approximator.parameters())

@@ -44,9 +44,9 @@ class ValueFunctionApproximator(torch.nn.Module):
     with ReLU between them so that V(xf) = 0 (reference vhjb.py:17-60).  Kernels are stored
     (in, out) and applied as `x @ W`, like Flax.  `activation` "sin" / "tanh" give the notebook variants
     (examples/double_integrator_optimal_time.ipynb cell 5, examples/cartpole_balancing.ipynb): odd functions
-    with act(0) = 0, so V(xf) = 0 still holds; the fused MFMA kernels exist for "relu" and "tanh"."""
+    with act(0) = 0, so V(xf) = 0 still holds; the fused MFMA kernels exist for all three."""
 
-    FUSED_ACTIVATIONS = ("relu", "tanh")   # hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 exist for these
+    FUSED_ACTIVATIONS = ("relu", "tanh", "sin")   # hjbx_value_grad_f32 / hjbx_vhjb_rollout_f32 exist for these
     _ACT = {"relu": (torch.relu, lambda a: (a > 0).to(a.dtype)),
             "sin": (torch.sin, torch.cos),
             "tanh": (torch.tanh, lambda a: 1.0 - torch.tanh(a) ** 2)}
@@ -145,7 +145,7 @@ class ValueFunctionApproximator(torch.nn.Module):
     def fused_value_grad(self, x: torch.Tensor, want_v=True, want_grad=True):
         """Inference-only V and dV/dx from the fused MFMA kernel (float32)."""
         if self.activation not in self.FUSED_ACTIVATIONS:
-            raise NotImplementedError(f"no fused value-gradient kernel for the {self.activation} activation (relu and tanh only)")
+            raise NotImplementedError(f"no fused value-gradient kernel for the {self.activation} activation")
         for w in self.weights:
             assert w.is_contiguous() and w.dtype == torch.float32
         return _ops.value_grad(self.dynamics.system, self.descriptor(), x, want_v, want_grad)
@@ -291,7 +291,7 @@ class VHJBController(Controller):
         self.value_function_approximator = ValueFunctionApproximator(
             dynamics, config.features, config.normalization_mean, config.normalization_std, self.xf, config.epsilon_scalar,
             config.using_batch_norm, dtype=dtype, device=self.device, generator=self._init_gen, activation=activation)
-        # activation: "relu" = controller/vhjb.py; "tanh" / "sin" = the notebooks' networks ("sin": PyTorch path only)
+        # activation: "relu" = controller/vhjb.py; "tanh" / "sin" = the notebooks' networks
         # the matrix-core kernels carry the five built-in systems; a user-defined system (Dynamics.device_source) runs the value network
         # through PyTorch and its own run-time compiled step / residual kernels
         builtin = dynamics.system.kind != _abi.SYS_USER
@@ -300,15 +300,16 @@ class VHJBController(Controller):
         if self.fused_value_grad and not fusable:
             raise NotImplementedError(f"no fused value-gradient kernel for the {activation} activation")
         # the parameter gradient of the optimiser step: hand-written MFMA kernels (hjbx_value_loss_grad_f32: forward, input gradient,
-        # residuals and the second-order reverse sweep in closed form) for the float32 ReLU network of controller/vhjb.py and the tanh network
-        # of examples/cartpole_balancing.ipynb; anything else (float64, sin, HJBX_FUSED_PARAM_GRAD=0) goes through PyTorch autograd
-        can_fuse_pg = (dtype == torch.float32 and activation in ("relu", "tanh") and tuple(config.features) == (128, 128, 64) and self.device.type == "cuda"
-                       and not config.using_batch_norm and builtin)
+        # residuals and the second-order reverse sweep in closed form) for the float32 ReLU network of controller/vhjb.py, the tanh network
+        # of examples/cartpole_balancing.ipynb and (state dimension <= 4) the sin network of examples/double_integrator_optimal_time.ipynb;
+        # anything else (float64, HJBX_FUSED_PARAM_GRAD=0) goes through PyTorch autograd
+        can_fuse_pg = (dtype == torch.float32 and (activation in ("relu", "tanh") or (activation == "sin" and self.state_dim <= 4))
+                       and tuple(config.features) == (128, 128, 64) and self.device.type == "cuda" and not config.using_batch_norm and builtin)
         if fused_param_grad is None:
             fused_param_grad = can_fuse_pg and os.environ.get("HJBX_FUSED_PARAM_GRAD", "1") != "0"
         if fused_param_grad and not can_fuse_pg:
-            raise NotImplementedError("the fused parameter-gradient kernels exist for float32 ReLU / tanh networks with features [128, 128, 64] on the "
-                                      "built-in systems only")
+            raise NotImplementedError("the fused parameter-gradient kernels exist for float32 ReLU / tanh / sin (n <= 4) networks with features "
+                                      "[128, 128, 64] on the built-in systems only")
         self.fused_param_grad = bool(fused_param_grad)
         # fused rollouts of big batches re-pack live environments every `compaction_interval` steps (0 = never)
         self.compaction_interval, self.compaction_min_batch = 16, 8192
@@ -560,15 +561,7 @@ class VHJBController(Controller):
         return flat
 
     def _adam_state(self, params):
-        """(exp_avg list, exp_avg_sq list, step list) of torch.optim.Adam for the three weight matrices, created the way its fused implementation
-        creates them if no step has run yet (zeros; the step counts float32 device scalars)."""
-        st = self.optimizer.state
-        for p in params:
-            if len(st[p]) == 0:
-                st[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        return [st[p]["exp_avg"] for p in params], [st[p]["exp_avg_sq"] for p in params], [st[p]["step"] for p in params]
+        return adam_state(self.optimizer, params)
 
     def _update_core(self, xs, dones, costs, regularization, loss_accum=None, step_counter=None):
         """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph.  loss_accum / step_counter
@@ -766,6 +759,18 @@ class GraphedStep:
                 buf.copy_(t)
         self.graph.replay()
         return self.out
+
+
+def adam_state(optimizer, params):
+    """(exp_avg list, exp_avg_sq list, step list) of a torch.optim.Adam for `params`, created the way its fused / capturable implementation
+    creates them if no step has run yet (zeros; the step counts float32 device scalars) -- the tensors hjbx_mix_adam_f32 updates in place."""
+    st = optimizer.state
+    for p in params:
+        if len(st[p]) == 0:
+            st[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return [st[p]["exp_avg"] for p in params], [st[p]["exp_avg_sq"] for p in params], [st[p]["step"] for p in params]
 
 
 def capture_step(optimizer, params, step_fn, dev, before_each=None):

@@ -45,14 +45,14 @@ using namespace hjbx;
 // launch shape: TL tiles of 32 environments per wave, WAVES waves per workgroup (one workgroup per CU).
 //   (TL, WAVES) = (1, 8): two waves per SIMD, 256 VGPRs each.   (2, 4): one wave per SIMD, 512 VGPRs.
 // This file is compiled once per variant (-DHJBX_MLP_ACT=0 relu, =1 tanh, =2 relu with the bf16x3-split arithmetic of hjbx_mlp_x3.hpp,
-// =3 relu with the f16x2-split arithmetic of hjbx_mlp_h2.hpp: 30 kernel instantiations each, side by side); the relu object also
+// =3 relu with the f16x2-split arithmetic of hjbx_mlp_h2.hpp, =4 sin: 30 kernel instantiations each, side by side); the relu object also
 // carries the two C entry points, which validate and hand over to the object of the requested variant.
 #ifndef HJBX_MLP_ACT
-#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points), =1 (tanh), =2 (relu, bf16x3-split MFMA) and =3 (relu, f16x2-split MFMA)"
+#error "compile hjbx_mlp.hip with -DHJBX_MLP_ACT=0 (relu + the C entry points), =1 (tanh), =2 (relu, bf16x3-split MFMA), =3 (relu, f16x2-split MFMA) and =4 (sin)"
 #endif
 static constexpr int kArith = HJBX_MLP_ACT == 2 ? 1 : HJBX_MLP_ACT == 3 ? 2 : 0;  // 0 = f32 MFMA, 1 = bf16x3, 2 = f16x2 (HJBX_OPT_MLP_ARITHMETIC)
-static constexpr int kAct = kArith ? HJBX_ACT_RELU : HJBX_MLP_ACT;
-static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH, "fused kernels exist for relu and tanh");
+static constexpr int kAct = kArith ? HJBX_ACT_RELU : HJBX_MLP_ACT == 4 ? HJBX_ACT_SIN : HJBX_MLP_ACT;
+static_assert(kAct == HJBX_ACT_RELU || kAct == HJBX_ACT_TANH || kAct == HJBX_ACT_SIN, "fused kernels exist for relu, tanh and sin");
 template <int N, int AR> using MlpLdsT = std::conditional_t<AR == 1, MlpLdsX3<N>, std::conditional_t<AR == 2, MlpLdsH2<N>, MlpLds<N>>>;
 #define HJBX_MLP_CAT2(a, b) a##b
 #define HJBX_MLP_CAT(a, b) HJBX_MLP_CAT2(a, b)
@@ -63,6 +63,7 @@ HJBX_HIDDEN int hjbx_mlp_value_grad_act0(const hjbx_system*, const hjbx_mlp*, co
 HJBX_HIDDEN int hjbx_mlp_value_grad_act1(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_value_grad_act2(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_value_grad_act3(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
+HJBX_HIDDEN int hjbx_mlp_value_grad_act4(const hjbx_system*, const hjbx_mlp*, const float*, float*, float*, int64_t, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act3(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
                                       float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act2(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
@@ -70,6 +71,8 @@ HJBX_HIDDEN int hjbx_mlp_rollout_act2(const hjbx_system*, const hjbx_task*, cons
 HJBX_HIDDEN int hjbx_mlp_rollout_act0(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
                                       float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 HJBX_HIDDEN int hjbx_mlp_rollout_act1(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
+                                      float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
+HJBX_HIDDEN int hjbx_mlp_rollout_act4(const hjbx_system*, const hjbx_task*, const hjbx_mlp*, int, int, int, int, const float*, float*, float*, float*,
                                       float*, float*, int32_t*, float*, const int32_t*, int64_t, void*, void*);
 
 #ifndef HJBX_MLP_TL
@@ -379,9 +382,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_vhjb_rollout_mfma(S s
 #if HJBX_MLP_ACT == 0
 extern "C" size_t hjbx_rollout_workspace_bytes(void) { return (size_t)kWsWords * sizeof(unsigned); }
 static int check_activation(const hjbx_mlp* mlp, const char* who) {
-    if (mlp->activation == HJBX_ACT_RELU || mlp->activation == HJBX_ACT_TANH) return HJBX_OK;
-    if (mlp->activation == HJBX_ACT_SIN)
-        return hjbx_set_error(HJBX_EUNSUPPORTED, "%s: no fused kernel for the sin activation (its derivative needs the pre-activations)", who);
+    if (mlp->activation == HJBX_ACT_RELU || mlp->activation == HJBX_ACT_TANH || mlp->activation == HJBX_ACT_SIN) return HJBX_OK;
     return hjbx_set_error(HJBX_EINVAL, "%s: unknown activation %d", who, mlp->activation);
 }
 #endif
@@ -451,6 +452,7 @@ extern "C" int hjbx_value_grad_f32(const hjbx_system* sys, const hjbx_mlp* mlp, 
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_grad_f32: normalization_std[%d] is zero", k);
     if (mlp->activation == HJBX_ACT_TANH) return hjbx_mlp_value_grad_act1(sys, mlp, x, V, g, B, stream);
+    if (mlp->activation == HJBX_ACT_SIN) return hjbx_mlp_value_grad_act4(sys, mlp, x, V, g, B, stream);
     const int arith = hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC);
     return arith == 1 ? hjbx_mlp_value_grad_act2(sys, mlp, x, V, g, B, stream)
          : arith == 2 ? hjbx_mlp_value_grad_act3(sys, mlp, x, V, g, B, stream)
@@ -552,6 +554,8 @@ extern "C" int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* ta
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_vhjb_rollout_f32: normalization_std[%d] is zero", k);
     if (mlp->activation == HJBX_ACT_TANH)
         return hjbx_mlp_rollout_act1(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
+    if (mlp->activation == HJBX_ACT_SIN)
+        return hjbx_mlp_rollout_act4(sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);
     const int arith = hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC);
     return (arith == 1 ? hjbx_mlp_rollout_act2 : arith == 2 ? hjbx_mlp_rollout_act3 : hjbx_mlp_rollout_act0)(
         sys, task, mlp, integrator, t_first, n_steps, T_max, x, traj, u_log, cost, done, resid, done_step, x_out, env_order, B, workspace, stream);

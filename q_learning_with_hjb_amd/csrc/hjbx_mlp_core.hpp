@@ -42,14 +42,41 @@ __device__ __forceinline__ float tanh1(float v) {
     const float ex = __builtin_amdgcn_exp2f(v * 2.8853900817779268f);  // exp(2x) = 2^(2x log2 e)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(ex + 1.0f);
 }
+// sin / cos for the time-optimal notebook's network (hjbx_mlp.activation = HJBX_ACT_SIN), branch-free and without the stack frame of the
+// library's large-argument path (the matrix-core kernels must stay free of scratch): k = rint(x 2/pi), r = x - k pi/2 by a two-constant
+// Cody-Waite reduction under fma (exact for |k| < 2^12 or so: pre-activations are O(1) to O(100)), the Cephes single-precision minimax
+// polynomials on [-pi/4, pi/4] (about 1 ulp), quadrant by bit operations.  Absolute error ~1e-7 for |x| < 1e3.
+__device__ __forceinline__ void sincos1(float x, float& sn, float& cs) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371139000186243e-08f, r);
+    const float r2 = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), r2 * r2, fmaf(-0.5f, r2, 1.0f));
+    // quadrant without compares (a compare per element becomes an SGPR lane mask; 64 elements x 3 of them spill): odd k swaps the two
+    // polynomials through a bit-field insert under an all-ones / all-zeros mask, bits 1 of k and k + 1 go straight into the sign bits
+    const uint32_t q = (uint32_t)(int)k;
+    const uint32_t m = 0u - (q & 1u);
+    const uint32_t us = __builtin_bit_cast(uint32_t, ps), uc = __builtin_bit_cast(uint32_t, pc);
+    const uint32_t a = (uc & m) | (us & ~m), b = (us & m) | (uc & ~m);
+    sn = __builtin_bit_cast(float, a ^ ((q & 2u) << 30));
+    cs = __builtin_bit_cast(float, b ^ (((q + 1u) & 2u) << 30));
+}
+__device__ __forceinline__ float sin1(float x) { float s, c; sincos1(x, s, c); return s; }
+__device__ __forceinline__ float cos1(float x) { float s, c; sincos1(x, s, c); return c; }
+
 // ACT = hjbx_activation: the activation applied in place to a pre-activation, and the back-propagation factor d * act'(z)
-// written in terms of the ACTIVATION h = act(z) (relu: [h > 0]; tanh: 1 - h^2), so no pre-activation has to be kept
+// written in terms of the ACTIVATION h = act(z) (relu: [h > 0]; tanh: 1 - h^2), so no pre-activation has to be kept.
+// sin (examples/double_integrator_optimal_time.ipynb cell 5): act' = cos(z) cannot be had from sin(z) (the sign is lost), so the kernels
+// keep cos(z) where relu / tanh keep the activation: `h` of dact1 is then that cosine (sincos1 above).
 template <int ACT> __device__ __forceinline__ float act1(float v) {
     if constexpr (ACT == HJBX_ACT_TANH) return tanh1(v);
+    else if constexpr (ACT == HJBX_ACT_SIN) return sin1(v);
     else return relu1(v);
 }
 template <int ACT> __device__ __forceinline__ float dact1(float h, float d) {
     if constexpr (ACT == HJBX_ACT_TANH) return d - d * h * h;
+    else if constexpr (ACT == HJBX_ACT_SIN) return d * h;          // h = cos(z)
     // relu: d * [h > 0] as two multiplies, the first with the clamp output modifier (v_mul_f32 ... clamp gives exactly 1 for
     // every normal h > 0, and 0 for h <= 0 or NaN).  Same op count as v_cmp + v_cndmask, but no VCC in between: that pair
     // costs an s_nop per element (VALU write of VCC -> VALU read), 192 of them per tile and step.
@@ -240,18 +267,37 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[t][fb][r] = act1<ACT>(a1[t][fb][r]);
+            for (int r = 0; r < 16; ++r) {
+                a1[t][fb][r] = act1<ACT>(a1[t][fb][r]);
+                // sin: 64 independent polynomial evaluations -- left alone the scheduler interleaves them all and their temporaries spill
+                if constexpr (ACT == HJBX_ACT_SIN) {
+                    asm volatile("" : "+v"(a1[t][fb][r]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
     f32x16 a2[TL][4];
     zero_acc(a2);
     mfma_chain<OffW2F, 64, 4, 2, TL>(a2, ring4, c.w2f, [&](int st, int t) { return a1[t][st >> 4][st & 15]; });
 
     // ---- layer 3: Y' (64 x 32) = W3' . relu(H2') ------------------------------------------------------
+    f32x16 c2[ACT == HJBX_ACT_SIN ? TL : 1][ACT == HJBX_ACT_SIN ? 4 : 1];   // sin only: cos of layer 2's pre-activations
 #pragma unroll
     for (int t = 0; t < TL; ++t)
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a2[t][fb][r] = act1<ACT>(a2[t][fb][r]);  // the activation also carries act' for backward 2 (dact1)
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (ACT == HJBX_ACT_SIN) {   // sin for layer 3; cos kept for backward 2 (a1 is dead here: layer 1 is recomputed for backward 1)
+                    float sn, cs;
+                    sincos1(a2[t][fb][r], sn, cs);
+                    asm volatile("" : "+v"(sn), "+v"(cs));   // evaluated HERE: pure code is otherwise sunk to its uses (chain 3, backward 2) with the pre-activations kept alive
+                    a2[t][fb][r] = sn;
+                    c2[t][fb][r] = cs;
+                    __builtin_amdgcn_sched_barrier(0);   // (see layer 2)
+                } else {
+                    a2[t][fb][r] = act1<ACT>(a2[t][fb][r]);  // the activation also carries act' for backward 2 (dact1)
+                }
+            }
     f32x16 y[TL][2];
     zero_acc(y);
     mfma_chain<OffW3F, 64, 2, 2, TL>(y, ring2, c.w3f, [&](int st, int t) { return a2[t][st >> 4][st & 15]; });
@@ -286,7 +332,7 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2[t][fb][r] = dact1<ACT>(a2[t][fb][r], d2[t][fb][r]);
+            for (int r = 0; r < 16; ++r) d2[t][fb][r] = dact1<ACT>(ACT == HJBX_ACT_SIN ? c2[ACT == HJBX_ACT_SIN ? t : 0][ACT == HJBX_ACT_SIN ? fb : 0][r] : a2[t][fb][r], d2[t][fb][r]);
     f32x16 d1[TL][4];
     zero_acc(d1);
     mfma_chain<OffW2B, 64, 4, 2, TL>(d1, ring4, c.w2b, [&](int st, int t) { return d2[t][st >> 4][st & 15]; });
@@ -307,7 +353,11 @@ __device__ __forceinline__ void mlp_value_grad(const S& sys, const MlpP<S::N>& p
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const float dv = dact1<ACT>(ACT == HJBX_ACT_RELU ? a1[t][kb][s] : act1<ACT>(a1[t][kb][s]), d1[t][kb][s]);
+                float dv = dact1<ACT>(ACT == HJBX_ACT_RELU ? a1[t][kb][s] : ACT == HJBX_ACT_SIN ? cos1(a1[t][kb][s]) : act1<ACT>(a1[t][kb][s]), d1[t][kb][s]);
+                if constexpr (ACT == HJBX_ACT_SIN) {
+                    asm volatile("" : "+v"(dv));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const f32x2 dv2{dv, dv};
 #pragma unroll
                 for (int q = 0; q < NP / 4; ++q) {

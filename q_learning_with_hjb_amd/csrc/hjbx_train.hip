@@ -617,7 +617,7 @@ static int launch_train(const hjbx_system* sysh, S sys, const hjbx_task* task, c
 // f16x2 value-network arithmetic is selected (its split-operand chains live in the round-2 pair of kernels below) or HJBX_OPT_TRAIN_KERNEL = 1
 // asks for that pair (A/B measurements); tanh networks exist in the cooperative kernel only
 static bool use_two_kernels(int activation) {
-    if (activation == HJBX_ACT_TANH) return false;
+    if (activation == HJBX_ACT_TANH || activation == HJBX_ACT_SIN) return false;
     return hjbx_option_value(HJBX_OPT_MLP_ARITHMETIC) == 2 || hjbx_option_value(HJBX_OPT_TRAIN_KERNEL) == 1;
 }
 
@@ -645,9 +645,8 @@ extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task*
         return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x, cost, done, workspace and the weights must be non-NULL");
     if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2, mlp->h3);
-    if (mlp->activation != HJBX_ACT_RELU && mlp->activation != HJBX_ACT_TANH)
-        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: the fused parameter-gradient kernels exist for relu (controller/vhjb.py) and tanh "
-                                                 "(examples/cartpole_balancing.ipynb) networks; sin goes through autograd");
+    if (mlp->activation != HJBX_ACT_RELU && mlp->activation != HJBX_ACT_TANH && mlp->activation != HJBX_ACT_SIN)
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: unknown activation %d", mlp->activation);
     const size_t row = (size_t)sys->n * sizeof(float);
     const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
     if ((reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(workspace) & 255u))

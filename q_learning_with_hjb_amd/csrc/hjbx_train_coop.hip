@@ -1,12 +1,13 @@
 // hjbx_train_coop.hip -- the parameter gradient of the value-learning step (reference controller/vhjb.py:227-253, 282-284) in ONE kernel with
 // NO scratch in HBM (round 3; hjbx_train.hip holds the round-2 pair of kernels, which moved 10 KB per sample through HBM and walked a tile's
-// 1,552 MFMAs on one wave).  ReLU (controller/vhjb.py) and tanh (examples/cartpole_balancing.ipynb cell 6) networks, float32 MFMA.
+// 1,552 MFMAs on one wave).  ReLU (controller/vhjb.py), tanh (examples/cartpole_balancing.ipynb cell 6) and sin
+// (examples/double_integrator_optimal_time.ipynb cell 5) networks, float32 MFMA.
 //
-// Math per sample (s = act'(a); ReLU: act'' = 0, tanh: act'' = -2 h s), q = d loss_hjb / d gradV, r = d loss_term / d V:
+// Math per sample (s = act'(a); ReLU: act'' = 0, tanh: act'' = -2 h s, sin: act'' = -h), q = d loss_hjb / d gradV, r = d loss_term / d V:
 //   forward            h1 = act(W1'z)   h2 = act(W2'h1)   y = W3'h2   V = |y|^2 + eps_s |e|^2
 //   input gradient     dy = 2y   d2 = (W3 dy).s2   d1 = (W2 d2).s1   g = (W1 d1)/std + 2 eps_s e
 //   reverse sweep (q)  gzb = q/std   t1 = W1'gzb   dh1b = t1.s1   t2 = W2'dh1b   dh2b = t2.s2   yb = 2 W3'dh2b
-//                      a2b = (W3 yb).s2 - 2 h2.d2.t2 [tanh]      a1b = (W2 a2b).s1 - 2 h1.d1.t1 [tanh]
+//                      a2b = (W3 yb).s2 - 2 h2.d2.t2 [tanh] - h2.(W3 dy).t2 [sin]      a1b = (W2 a2b).s1 - 2 h1.d1.t1 [tanh] - h1.(W2 d2).t1 [sin]
 //   hjb gradient       dW1 = gzb (x) d1 + z (x) a1b      dW2 = dh1b (x) d2 + h1 (x) a2b      dW3 = dh2b (x) dy + h2 (x) yb
 //   termination grad.  dW1 = z (x) (r d1)                dW2 = h1 (x) (r d2)                 dW3 = h2 (x) (r dy)
 // (the second-order terms of tanh: the adjoint of s = 1 - h^2 is (adjoint of d).(W d_next) and d s / d a = -2 h s, so a_bar gains
@@ -289,9 +290,21 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         // ---- 1. h1 = act(W1'z): B operands are this lane's own z ------------------------------------------------------------------------
         zero_acc(t);
         mfma_chain<OffW1Fc, N / 2, 1, 2, 1>(t, ring1, aW1f, [&](int st, int) { return h ? z[2 * st + 1] : z[2 * st]; });
-        f32x16 h1r;
+        constexpr bool SIN = ACT == HJBX_ACT_SIN;   // act' = cos(a) is kept beside the activation (s1r, s2r); relu / tanh derive it from the activation
+        f32x16 h1r, s1r;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1r[r] = act1<ACT>(t[0][0][r]);
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (SIN) {
+                float sn, cs;
+                sincos1(t[0][0][r], sn, cs);
+                asm volatile("" : "+v"(sn), "+v"(cs));   // evaluated here, not sunk to the uses (see mlp_value_grad)
+                h1r[r] = sn;
+                s1r[r] = cs;
+            } else {
+                h1r[r] = act1<ACT>(t[0][0][r]);
+            }
+        }
+        auto dmul1 = [&](int r, float v) __attribute__((always_inline)) { if constexpr (SIN) return v * s1r[r]; else return dact1<ACT>(h1r[r], v); };
         ex_write(E0 + exW, h1r);
         COOP_SYNC();                                                                    // (A) E0 = h1
         // ---- 2. h2 = act(W2'h1) -------------------------------------------------------------------------------------------------------
@@ -326,9 +339,20 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #endif
             COOP_CHAIN(coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB), w1_part2);)
         }
-        f32x16 h2r;
+        f32x16 h2r, s2r;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2r[r] = act1<ACT>(acc[r]);
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (SIN) {
+                float sn, cs;
+                sincos1(acc[r], sn, cs);
+                asm volatile("" : "+v"(sn), "+v"(cs));
+                h2r[r] = sn;
+                s2r[r] = cs;
+            } else {
+                h2r[r] = act1<ACT>(acc[r]);
+            }
+        }
+        auto dmul2 = [&](int r, float v) __attribute__((always_inline)) { if constexpr (SIN) return v * s2r[r]; else return dact1<ACT>(h2r[r], v); };
         ex_write(E1 + exW, h2r);
         COOP_SYNC();                                                                    // (B) E1 = h2
         // ---- 3. y = W3'h2: block ob, contraction half kh; halves summed through E2; V, r --------------------------------------------------
@@ -363,16 +387,24 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         zero16(acc);
         COOP_CHAIN(coop_chain<2 * 4, BOX, 32>(acc, aW3b, lds3(E0 + exB));)
         f32x16 d2r;
+        f32x16 c2r;                                                                         // second-order term of a2b (tanh, sin), completed at step 7
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d2r[r] = dact1<ACT>(h2r[r], acc[r]);
+        for (int r = 0; r < 16; ++r) {
+            d2r[r] = dmul2(r, acc[r]);
+            if constexpr (SIN) c2r[r] = -h2r[r] * acc[r];                                   // act'' (W3 dy) = -sin(a2) . (pre-mask value)
+        }
         ex_write(E1 + exW, d2r);                                                            // (h2's readers finished before (C))
         COOP_SYNC();                                                                    // (E) E1 = d2, rs
         // ---- 5. d1 = (W2 d2).s1; g = W1 d1 / std + 2 eps_s e; the hjb residual ------------------------------------------------------------
         zero16(acc);
         COOP_CHAIN(coop_chain<2 * 4, BOX, 64>(acc, aW2b, lds3(E1 + exB));)
         f32x16 d1r;
+        f32x16 c1r;                                                                         // second-order term of a1b (tanh, sin), completed at step 6
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d1r[r] = dact1<ACT>(h1r[r], acc[r]);
+        for (int r = 0; r < 16; ++r) {
+            d1r[r] = dmul1(r, acc[r]);
+            if constexpr (SIN) c1r[r] = -h1r[r] * acc[r];
+        }
         ex_write(E2 + exW, d1r);                                                            // (the partial y's readers finished before (D))
         zero_acc(t);
         mfma_chain<OffW1Gc, 16, 1, 2, 1>(t, ring1, aW1g, [&](int st, int) { return d1r[st]; });
@@ -415,12 +447,12 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         // ---- 6. t1 = W1'gzb, dh1b = t1.s1 (B operands: this lane's own gzb) ---------------------------------------------------------------
         zero_acc(t);
         mfma_chain<OffW1Fc, N / 2, 1, 2, 1>(t, ring1, aW1f, [&](int st, int) { return h ? gzb[2 * st + 1] : gzb[2 * st]; });
-        f32x16 c1r;                                                                         // tanh: -2 h1 . d1 . t1 (second-order term of a1b)
-        f32x16 dh1b;
+        f32x16 dh1b;                                                                        // tanh: c1 = -2 h1 . d1 . t1; sin: c1 = -h1 . (W2 d2) . t1
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if constexpr (ACT == HJBX_ACT_TANH) c1r[r] = -2.f * h1r[r] * d1r[r] * t[0][0][r];
-            dh1b[r] = dact1<ACT>(h1r[r], t[0][0][r]);
+            if constexpr (SIN) c1r[r] *= t[0][0][r];
+            dh1b[r] = dmul1(r, t[0][0][r]);
         }
         COOP_SYNC();                                                                    // (G) zs, gzbs visible; partial g read
         ex_write(E0 + exW, dh1b);
@@ -460,12 +492,12 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         // ---- 7. t2 = W2'dh1b, dh2b = t2.s2 -------------------------------------------------------------------------------------------------
         zero16(acc);
         COOP_CHAIN(coop_chain<AO1, BOX, 64>(acc, aW2f, lds3(E0 + exB));)
-        f32x16 c2r;
         f32x16 dh2b;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if constexpr (ACT == HJBX_ACT_TANH) c2r[r] = -2.f * h2r[r] * d2r[r] * acc[r];
-            dh2b[r] = dact1<ACT>(h2r[r], acc[r]);
+            if constexpr (SIN) c2r[r] *= acc[r];
+            dh2b[r] = dmul2(r, acc[r]);
         }
         COOP_SYNC();                                                                    // (J) the outer products above have read E1; d1 (E2) is used up
         ex_write(E1 + exW, dh2b);
@@ -495,8 +527,8 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         f32x16 a2b;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            a2b[r] = dact1<ACT>(h2r[r], acc[r]);
-            if constexpr (ACT == HJBX_ACT_TANH) a2b[r] += c2r[r];
+            a2b[r] = dmul2(r, acc[r]);
+            if constexpr (ACT != HJBX_ACT_RELU) a2b[r] += c2r[r];
         }
         COOP_SYNC();                                                                    // (N) the outer products above have read E1, E2
         ex_write(E2 + exW, a2b);
@@ -510,8 +542,8 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         f32x16 a1b;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            a1b[r] = dact1<ACT>(h1r[r], acc[r]);
-            if constexpr (ACT == HJBX_ACT_TANH) a1b[r] += c1r[r];
+            a1b[r] = dmul1(r, acc[r]);
+            if constexpr (ACT != HJBX_ACT_RELU) a1b[r] += c1r[r];
         }
         COOP_SYNC();                                                                    // (P) chain 10 and the outer products above have read E0, E1, E2
         ex_write(E2 + exW, a1b);   // read -- as the second part of dW1, z (x) a1b -- in the shadow of the NEXT tile's chain 2 (visible after its (A)), or below
@@ -667,14 +699,18 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
                 hipLaunchKernelGGL((k_train_coop<decltype(mode_c)::value, decltype(act_c)::value, 1, S>), dim3(w.grid), dim3(256), 0, s, sys, p, tk, lim, W1, W2, W3,
                                    x, cost, done, (float)task->eps, partial, partial_w1, sums, B, ntiles);
         };
-        const bool tanh_net = mlp->activation == HJBX_ACT_TANH;
-        if (mode == HJBX_RESIDUAL_NORMALISED) {
-            if (tanh_net) go(std::integral_constant<int, 0>{}, std::integral_constant<int, HJBX_ACT_TANH>{});
-            else go(std::integral_constant<int, 0>{}, std::integral_constant<int, HJBX_ACT_RELU>{});
-        } else {
-            if (tanh_net) go(std::integral_constant<int, 1>{}, std::integral_constant<int, HJBX_ACT_TANH>{});
-            else go(std::integral_constant<int, 1>{}, std::integral_constant<int, HJBX_ACT_RELU>{});
-        }
+        auto with_act = [&](auto mode_c) {
+            if (mlp->activation == HJBX_ACT_TANH) go(mode_c, std::integral_constant<int, HJBX_ACT_TANH>{});
+            else if (mlp->activation == HJBX_ACT_SIN) {
+                // sin keeps act' = cos(a) beside the activations (32 registers) and its second-order factors from steps 4 / 5 on: with the
+                // state-sized registers of a 6-D or 10-D residual that is 9-12 registers over the 512 of a wave -- n <= 4 only (the network
+                // belongs to the 2-D double integrator of the time-optimal notebook); larger systems keep the autograd path
+                if constexpr (N <= 4) go(mode_c, std::integral_constant<int, HJBX_ACT_SIN>{});
+            }
+            else go(mode_c, std::integral_constant<int, HJBX_ACT_RELU>{});
+        };
+        if (mode == HJBX_RESIDUAL_NORMALISED) with_act(std::integral_constant<int, 0>{});
+        else with_act(std::integral_constant<int, 1>{});
         const int nthreads = kCoopBlocks * 1024 + 2 * N * 128 + 4;
         hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, flat);
         hipError_t e = hipGetLastError();
@@ -686,6 +722,8 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
 // called by hjbx_value_loss_grad_f32 (hjbx_train.hip) after it has validated its arguments
 int hjbx_train_coop(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost, const float* done,
                     float* flat, void* workspace, int64_t B, void* stream) {
+    if (mlp->activation == HJBX_ACT_SIN && sys->n > 4)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: the sin network's fused parameter gradient exists for n <= 4 (n = %d)", sys->n);
     int rc = HJBX_EUNSUPPORTED;
 #ifdef HJBX_TRAIN_DEV   // development builds: cartpole and the 10-D quadcopter only
     bool ok = false;

@@ -140,7 +140,7 @@ def test_time_optimal_learner_trains_and_evaluates():
     d = _double_integrator()
     d.integrator = _abi.ZOH
     ctl = TimeOptimalVHJBController(d, activation="sin", num_states=4096, seed=0)
-    assert not ctl.fused
+    assert ctl.fused and ctl.fused_param_grad                # round 3: the sin network runs on the fused MFMA kernels (n <= 4 for the gradient)
     xs = ctl.states[:256].contiguous()
     # loss == mean |gradV . xdot + running cost| evaluated with plain torch
     with torch.no_grad():
@@ -158,6 +158,18 @@ def test_time_optimal_learner_trains_and_evaluates():
     gb = torch.autograd.grad(l2, params)
     for a, b in zip(ga, gb):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    # ... and == the fused kernel's gradient (hjbx_value_loss_grad_f32, RAW residual, done = 0) divided by the batch size; its loss sum too
+    z = torch.zeros(256, device="cuda")
+    flat = _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs, torch.ones_like(z), z, _abi.RESIDUAL_RAW)
+    off = 0
+    for b in gb:
+        k = b.numel()
+        fa = flat[off:off + k].view_as(b) / 256
+        assert float((fa - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7
+        off += k
+    P = off
+    assert abs(float(flat[2 * P]) / 256 - float(want)) < 1e-5 * max(1.0, float(want)) and float(flat[2 * P + 2]) == 256 and float(flat[2 * P + 3]) == 0
+    assert float(flat[P:2 * P].abs().max()) == 0.0           # no termination samples
     x0 = ctl.states[:64].clone()
     tt = ctl.time_to_target(x0, 2.0)
     assert torch.equal(x0, ctl.states[:64]) and tt.shape == (64,) and float(tt.max()) <= 2.0   # the caller's states are not stepped in place
@@ -180,12 +192,16 @@ def test_bad_law_is_refused():
         _ops.control_from_grad(d.system, task, x, x)
 
 
-def test_time_optimal_graphed_update_equals_eager():
-    """The learner's optimiser step replayed from a hipGraph == eager launches (same minibatches, same initial weights)."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_time_optimal_graphed_update_equals_eager(fused, monkeypatch):
+    """The learner's optimiser step replayed from a hipGraph == eager launches (same minibatches, same initial weights), through the fused
+    parameter gradient + Adam kernels and through PyTorch autograd (HJBX_FUSED_PARAM_GRAD=0)."""
+    monkeypatch.setenv("HJBX_FUSED_PARAM_GRAD", "1" if fused else "0")
     d = _double_integrator()
     d.integrator = _abi.ZOH
     a = TimeOptimalVHJBController(d, activation="sin", num_states=2048, seed=5)
     b = TimeOptimalVHJBController(d, activation="sin", num_states=2048, seed=5)
+    assert a.fused_param_grad == fused
     pa, pb = list(a.value_function_approximator.parameters()), list(b.value_function_approximator.parameters())
     assert all(torch.equal(x, y) for x, y in zip(pa, pb)) and torch.equal(a.states, b.states)
     start = [p.detach().clone() for p in pa]
@@ -199,3 +215,27 @@ def test_time_optimal_graphed_update_equals_eager():
     assert all(float((p - s).abs().max()) > 1e-3 for p, s in zip(pa, start))
     # a ragged last minibatch falls back to eager launches
     assert np.isfinite(float(a.params_update_graphed(a.states[:100].contiguous())))
+
+
+def test_time_optimal_fused_and_autograd_updates_agree(monkeypatch):
+    """Five updates of the sin learner through the fused kernels (hjbx_value_loss_grad_f32 + hjbx_mix_adam_f32) against five through autograd +
+    torch.optim.Adam: same minibatches, losses to 1e-4, weights to a few percent of what they moved (Adam's first steps are +-lr sign(g):
+    entries with |g| ~ 1e-8 may differ in sign)."""
+    d = _double_integrator()
+    d.integrator = _abi.ZOH
+    ctls = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HJBX_FUSED_PARAM_GRAD", fused)
+        ctls.append(TimeOptimalVHJBController(d, activation="sin", num_states=2048, seed=5))
+    a, b = ctls
+    assert a.fused_param_grad and not b.fused_param_grad
+    pa, pb = list(a.value_function_approximator.parameters()), list(b.value_function_approximator.parameters())
+    start = [p.detach().clone() for p in pa]
+    for k in range(5):
+        xs = a.states[256 * k:256 * (k + 1)].contiguous()
+        la, lb = float(a.params_update(xs)), float(b.params_update(xs))
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)), (k, la, lb)
+    for x, y, s0 in zip(pa, pb, start):
+        moved = float((y - s0).abs().max())
+        diff = (x - y).abs()
+        assert float(diff.median()) <= 0.02 * moved and float((diff > 0.5 * moved).float().mean()) < 0.01

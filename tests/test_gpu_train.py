@@ -182,17 +182,25 @@ def test_fused_and_autograd_updates_agree():
 @pytest.mark.parametrize("mode", [_abi.RESIDUAL_NORMALISED, _abi.RESIDUAL_RAW])
 @pytest.mark.parametrize("B", [33, 256, 1000])
 @pytest.mark.parametrize("name", SYSTEMS)
-def test_value_loss_grad_tanh_network_vs_f64_autograd(name, B, mode):
-    """The tanh network of examples/cartpole_balancing.ipynb cell 6 in the fused kernel: act'' != 0 adds the second-order terms
-    -2 h . d . t to the reverse sweep (derivation at the top of csrc/hjbx_train_coop.hip).  Against float64 torch.autograd double back-prop of
-    the plain loss formulas with torch.tanh, same bounds as the ReLU network: 1e-4 of each matrix's largest entry and 1e-4 in Frobenius norm.
-    Both residual modes (the notebook trains with the RAW residual, cell 11)."""
-    d, ctl = controller(name, activation="tanh", residual_mode=mode)
-    assert ctl.fused_param_grad
+@pytest.mark.parametrize("activation", ["tanh", "sin"])
+def test_value_loss_grad_tanh_network_vs_f64_autograd(activation, name, B, mode):
+    """The tanh network of examples/cartpole_balancing.ipynb cell 6 and the sin network of examples/double_integrator_optimal_time.ipynb
+    cell 5 in the fused kernel: act'' != 0 adds the second-order terms (tanh: -2 h . d . t; sin: -h . (W d_next) . t) to the reverse sweep
+    (derivation at the top of csrc/hjbx_train_coop.hip).  Against float64 torch.autograd double back-prop of the plain loss formulas with
+    torch.tanh / torch.sin, same bounds as the ReLU network: 1e-4 of each matrix's largest entry and 1e-4 in Frobenius norm.  Both residual
+    modes (the notebooks train with the RAW residual).  sin exists for state dimensions <= 4: the 6-D and 10-D systems keep autograd."""
+    d, ctl = controller(name, activation=activation, residual_mode=mode)
     vf = ctl.value_function_approximator
+    if activation == "sin" and d.state_dim > 4:
+        assert not ctl.fused_param_grad
+        xs, dones, costs = _batch(d, ctl, 64, 41)
+        with pytest.raises(NotImplementedError):
+            _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs, costs, dones, mode=mode)
+        return
+    assert ctl.fused_param_grad
     with torch.no_grad():
         for w in vf.weights:
-            w.mul_(1.5)                                        # part of the units towards saturation: h^2 and the -2 h d t terms matter
+            w.mul_(1.5)                                        # part of the units towards saturation: h^2 and the second-order terms matter
     xs, dones, costs = _batch(d, ctl, B, 41)
     flat = _ops.value_loss_grad(d.system, ctl._task, vf.descriptor(), xs, costs, dones, mode=mode)
     gh, gt, sc = _unpack(flat, d.state_dim)
@@ -207,19 +215,20 @@ def test_value_loss_grad_tanh_network_vs_f64_autograd(name, B, mode):
                 assert np.abs(a).max() == 0
                 continue
             err = np.abs(a - b)
-            assert err.max() <= 1e-4 * scale, f"tanh {label} dW{k + 1}: max err {err.max():.3e} vs scale {scale:.3e} (rel {err.max() / scale:.2e})"
-            assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), f"tanh {label} dW{k + 1}: Frobenius rel {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
+            assert err.max() <= 1e-4 * scale, f"{activation} {label} dW{k + 1}: max err {err.max():.3e} vs scale {scale:.3e} (rel {err.max() / scale:.2e})"
+            assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), f"{activation} {label} dW{k + 1}: Frobenius rel {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
     # the second-order terms are really there: dropping them (= treating tanh like a piecewise-linear unit) would be far outside the bound
     if B == 256 and mode == _abi.RESIDUAL_NORMALISED:
         assert np.abs(rh[1].cpu().numpy()).max() > 0
 
 
-def test_tanh_updates_through_the_fused_kernels_match_autograd():
-    """params_update of a tanh controller (the notebook recipe that reproduces the reference's cartpole anchor) through the fused kernels ==
-    through PyTorch autograd: losses to 1e-5, gradients to 1e-4 of each matrix's largest entry."""
+@pytest.mark.parametrize("activation", ["tanh", "sin"])
+def test_tanh_updates_through_the_fused_kernels_match_autograd(activation):
+    """params_update of a tanh controller (the notebook recipe that reproduces the reference's cartpole anchor; likewise sin) through the fused
+    kernels == through PyTorch autograd: losses to 1e-5, gradients to 1e-4 of each matrix's largest entry."""
     res = {}
     for fused in (True, False):
-        d, ctl = controller("cartpole", activation="tanh", fused_param_grad=fused, graph_updates=False, residual_mode=_abi.RESIDUAL_RAW)
+        d, ctl = controller("cartpole", activation=activation, fused_param_grad=fused, graph_updates=False, residual_mode=_abi.RESIDUAL_RAW)
         assert ctl.fused_param_grad == fused
         xs, dones, costs = _batch(d, ctl, 256, 3)
         grads = _mixed_grads(ctl, xs, dones, costs, 0.37) if fused else None
@@ -233,14 +242,15 @@ def test_tanh_updates_through_the_fused_kernels_match_autograd():
 
 
 def test_value_loss_grad_rejects_what_it_cannot_do():
-    d, ctl = controller("cartpole", activation="sin")
+    d, ctl = controller("nearhover", activation="sin")          # sin: state dimensions <= 4 only
     xs, dones, costs = _batch(d, ctl, 64, 1)
     with pytest.raises(NotImplementedError):
         _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs, costs, dones)
-    assert not ctl.fused_param_grad                              # the controller falls back to autograd for sin on its own
+    assert not ctl.fused_param_grad                              # the controller falls back to autograd there on its own
     with pytest.raises(NotImplementedError):
-        controller("cartpole", activation="sin", fused_param_grad=True)
+        controller("nearhover", activation="sin", fused_param_grad=True)
     d, ctl = controller("cartpole", activation="tanh")
+    xs, dones, costs = _batch(d, ctl, 64, 1)
     prev = _abi.set_option(_abi.OPT_TRAIN_KERNEL, 1)             # tanh exists in the cooperative kernel only: the option does not apply to it
     try:
         flat = _ops.value_loss_grad(d.system, ctl._task, ctl.value_function_approximator.descriptor(), xs, costs, dones)

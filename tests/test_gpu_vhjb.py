@@ -607,12 +607,14 @@ def test_compaction_makes_finished_environments_cheap():
 
 
 @pytest.mark.parametrize("B", [33, 5000])
-@pytest.mark.parametrize("name", ["cartpole", "quad2d", "nearhover"])
-def test_tanh_network_fused_kernels_vs_oracle_and_torch(name, B):
-    """hjbx_mlp.activation = HJBX_ACT_TANH (the network of examples/cartpole_balancing.ipynb cell 6): the fused value-gradient
-    kernel against the f64 oracle (exact tanh) and against the PyTorch graph, and the fused rollout kernel bit-identical to
-    value_grad + vhjb_step step by step.  The kernel's tanh is 1 - 2/(exp(2x)+1) on the exp2 / rcp units (abs err ~1e-7)."""
-    d, ctl = controller(name, torch.float32, activation="tanh")
+@pytest.mark.parametrize("name", ["linear", "cartpole", "quad2d", "nearhover"])
+@pytest.mark.parametrize("activation", ["tanh", "sin"])
+def test_tanh_network_fused_kernels_vs_oracle_and_torch(activation, name, B):
+    """hjbx_mlp.activation = HJBX_ACT_TANH (the network of examples/cartpole_balancing.ipynb cell 6) and HJBX_ACT_SIN (the network of
+    examples/double_integrator_optimal_time.ipynb cell 5): the fused value-gradient kernel against the f64 oracle (exact tanh / sin / cos)
+    and against the PyTorch graph, and the fused rollout kernel bit-identical to value_grad + vhjb_step step by step.  The kernel's tanh
+    is 1 - 2/(exp(2x)+1) on the exp2 / rcp units, its sin / cos a two-constant reduction + minimax polynomials (abs err ~1e-7 each)."""
+    d, ctl = controller(name, torch.float32, activation=activation)
     assert ctl.fused_value_grad
     vf = ctl.value_function_approximator
     with torch.no_grad():
@@ -652,15 +654,15 @@ def test_tanh_network_fused_kernels_vs_oracle_and_torch(name, B):
     assert np.quantile(err.max(axis=(0, 2)), 0.99) < 2e-3 * scale and np.median(err.max(axis=(0, 2))) < 1e-4 * scale
 
 
-def test_sin_network_has_no_fused_kernel():
+def test_sin_network_runs_on_the_fused_kernels():
     d, ctl = controller("cartpole", torch.float32, activation="sin")
-    assert not ctl.fused_value_grad
+    assert ctl.fused_value_grad and ctl.fused_param_grad
     vf = ctl.value_function_approximator
     x = states_near_target(d, ctl, 64, 2, 1.0)
-    with pytest.raises(NotImplementedError):
-        vf.fused_value_grad(x)
-    with pytest.raises(NotImplementedError, match="sin"):
-        _ops.value_grad(d.system, vf.descriptor(), x, True, True)
+    V, g = vf.fused_value_grad(x)
+    with torch.no_grad():
+        tV, tg = vf.value_and_grad(x)
+    assert float((tV - V).abs().max()) <= 1e-5 * float(tV.abs().max()) and float((tg - g).abs().max()) <= 1e-5 * float(tg.abs().max())
     # the PyTorch path agrees with the oracle's sin / cos
     mlp, W = oracle_mlp(ctl)
     with torch.no_grad():

@@ -261,7 +261,7 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_asm_loads
     outs, procs = [], []
-    for act in (0, 1, 2, 3):                                  # one object per variant (relu, tanh, relu bf16x3, relu f16x2), compiled side by side
+    for act in (0, 1, 2, 3, 4):                               # one object per variant (relu, tanh, relu bf16x3, relu f16x2, sin), compiled side by side
         asm = tmp_path / f"mlp_act{act}.s"
         outs.append(asm)
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-S",
@@ -288,13 +288,13 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     assert audit_asm_loads.audit_mfma_asm_reads(str(probe)) == 1
     text = outs[0].read_text()
     assert text.count("v_mfma_f32_32x32x2_f32") > 10000 and "ds_read_b32" in text
-    # No MFMA inference kernel of ANY variant (f32 relu, f32 tanh, bf16x3, f16x2) may fall back on scratch: most sit at 250-256 VGPRs, a
+    # No MFMA inference kernel of ANY variant (f32 relu, f32 tanh, bf16x3, f16x2, f32 sin) may fall back on scratch: most sit at 250-256 VGPRs, a
     # spilled value is reloaded behind an `s_waitcnt vmcnt(0)` that drains the log stores, and round 2 saw rollout kernels whose spill
     # store sat in an EXEC = 0 region return wrong trajectories (the cause -- a divergent `grp` -- is removed as well).
     import re
     meta = re.compile(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)")
     for asm, mfma, per in ((outs[0], "v_mfma_f32_32x32x2_f32", 700), (outs[1], "v_mfma_f32_32x32x2_f32", 700), (outs[2], "v_mfma_f32_32x32x16_bf16", 288),
-                           (outs[3], "v_mfma_f32_32x32x16_f16", 288)):
+                           (outs[3], "v_mfma_f32_32x32x16_f16", 288), (outs[4], "v_mfma_f32_32x32x2_f32", 700)):
         text = asm.read_text()
         assert text.count(mfma) >= 30 * per
         kernels = meta.findall(text)
@@ -314,7 +314,8 @@ def test_inline_asm_lds_prefetch_is_register_safe(tmp_path):
     # and NO scratch (its first build hoisted ~200 loop-invariant LDS addresses out of the tile loop and spilled 78 of them)
     text = coop_asm.read_text()
     kernels = [k for k in meta.findall(text) if "k_train_coop" in k[0] and "reduce" not in k[0]]
-    assert len(kernels) == 9 * 4 * 2, len(kernels)             # 9 system instantiations x 2 residual modes x 2 activations x 2 tile splits (PS = 1, 4)
+    # 9 system instantiations x 2 residual modes x 2 activations (relu, tanh) x 2 tile splits (PS = 1, 4), + sin for the 6 systems with n <= 4
+    assert len(kernels) == 9 * 4 * 2 + 6 * 2 * 2, len(kernels)
     for name, private, _sgpr_spill, vgpr_spill in kernels:
         assert int(private) == 0 and int(vgpr_spill) == 0, f"{name}: {private} bytes of scratch, {vgpr_spill} spilled VGPRs"
     assert text.count("v_mfma_f32_32x32x2_f32") >= 36 * 690 + 36 * 400
