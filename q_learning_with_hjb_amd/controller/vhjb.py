@@ -13,6 +13,7 @@ in lock-step, state resident in HBM, time-major logs `(T+1, B, ...)`.
 from __future__ import annotations
 
 import math
+import weakref
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -800,8 +801,19 @@ def capture_step(optimizer, params, step_fn, dev, before_each=None):
                     v.copy_(saved_s[p][k]) if p in saved_s else v.zero_()
             p.grad = None
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
-        out = step_fn()
+    # no cyclic garbage collection while the stream is capturing: an unreachable CUDAGraph of an earlier controller collected in the middle
+    # of this capture calls hipGraphDestroy, which HIP refuses during a capture ("operation not permitted when stream is capturing") -- from
+    # a destructor, i.e. the process dies.  (torch.cuda.graph collects once on entry; allocations inside the capture can trigger it again.)
+    import gc
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=side):
+            out = step_fn()
+    finally:
+        if was_enabled:
+            gc.enable()
     return side, graph, out
 
 
@@ -828,17 +840,18 @@ class FitGraph:
         self.costs = torch.empty((batch,), dtype=torch.float32, device=dev)
         self.dones = torch.empty((batch,), dtype=torch.float32, device=dev)
         self.reg = torch.zeros((), dtype=torch.float32, device=dev)
-        self._ctl_ref = ctl
+        self._ctl_ref = weakref.ref(ctl)      # (no reference cycle: the graphs die with the controller, not at some later garbage collection)
         self._streams, self._graphs = [], {}
         self._capture(1)
 
     def _one_update(self):
-        ctl, rb = self._ctl_ref, self._ctl_ref.replay_buffer
+        ctl = self._ctl_ref()
+        rb = ctl.replay_buffer
         _ops.replay_gather(rb.x, rb.cost, rb.done, self.perm, self.step, self.reg_table, self.xs, self.costs, self.dones, self.reg)
         return ctl._update_core(self.xs, self.dones, self.costs, self.reg, loss_accum=self.loss_accum, step_counter=self.step)
 
     def _capture(self, count: int):
-        ctl = self._ctl_ref
+        ctl = self._ctl_ref()
 
         def step_fn():
             for _ in range(count):

@@ -182,3 +182,29 @@ def test_replay_gather_reads_its_minibatch_number_from_the_device():
     mixed0, losses0 = _ops.mix_gradients(flat, P, 0.25, 1e-7)
     assert torch.equal(mixed, mixed0) and torch.equal(losses, losses0) and int(step) == 8
     assert torch.allclose(acc, torch.tensor([1.0, 2.0, 3.0], device="cuda") + losses0, rtol=1e-7)
+
+
+def test_controllers_in_sequence_with_an_eager_garbage_collector():
+    """Captured graphs must not be destroyed while another capture is running (hipGraphDestroy is refused during a capture, and from a
+    destructor that ends the process -- seen under rocprofv3 in round 3, where the collector's timing differed): the fit graph holds its
+    controller weakly, so it dies with it, and capture_step keeps the cyclic collector off while the stream is capturing.  Three controllers
+    in a row, the collector set to run at every allocation."""
+    import gc
+    kw = dict(epochs=2, num_of_trajectories_per_epoch=4, maximum_step=30, batch_size=32, maximum_buffer_size=600)
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        counters = []
+        for k in range(3):
+            d = make_dynamics("cartpole")
+            ctl = VHJBController(d, make_vhjb_config("cartpole", **kw), dtype=torch.float32)
+            holder = [ctl]
+            holder.append(holder)                      # a reference cycle around the controller: only the cyclic collector can free it
+            ctl.train()
+            assert ctl._fit_graph is not None
+            counters.append(ctl.update_counter)
+            del ctl, holder
+        assert all(c > 0 for c in counters)
+    finally:
+        gc.set_threshold(*old)
+    torch.cuda.synchronize()

@@ -7,7 +7,7 @@ STAGE=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_r03
 mkdir -p $OUT
-R="rocprofv3 --output-format csv"
+R="timeout -k 10 400 rocprofv3 --output-format csv"   # (a profiled run that aborts can hang in the profiler's signal handler: bounded)
 if [ $STAGE != B ]; then
 # 1. kernel trace + stats of the bench command itself (default arithmetic = float32 MFMA; its secondary block runs the opt-in kernels too)
 $R --kernel-trace --stats -d $OUT/trace -- python3 bench.py > $OUT/bench_trace.json 2> $OUT/bench_trace.err || exit 1
