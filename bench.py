@@ -335,13 +335,24 @@ def param_gradient_kernels(system="nearhover", B=1 << 20):
     S = 128 * n + 128 * 128 + 128 * 64
     flops = 2.0 * (6 * S + 128 * 128 + 128 * 64)
     ach = flops * B / t / 1e12
+    from q_learning_with_hjb_amd import _abi
+    pair = ARITHMETIC == "f16x2" or _abi.set_option(_abi.OPT_TRAIN_KERNEL, -1) == 1      # (set_option(-1) only reads the option)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r03_train_coop_summary.json")
+    if not pair and os.path.exists(tpath):
+        with open(tpath) as f:
+            rec = json.load(f).get("k_train_coop<0, 0, PS, hjbx::%s<float>>" % dict(cartpole="Cartpole", nearhover="NearHover").get(system, ""), {})
+        traffic = rec.get("bytes_per_sample")
     return dict(name=f"value_loss_grad: parameter gradient of the learning step ({system}, B=2^{int(np.log2(B))})", ms=t * 1e3, samples_per_s=B / t,
                 achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F32_PEAK_TFLOPS, bound="mfma", flop_per_sample=flops,
-                scratch_bytes_per_sample=2 * 4.0 * 40960 / 32,
-                arithmetic=ARITHMETIC,
-                note="achieved = ALGORITHMIC float32 flops per second against the f32 MFMA peak; in the default arithmetic (f32) every product of both "
-                     "kernels runs on the f32 MFMA; with --arithmetic f16x2 the chains kernel runs its eight wide products as f16x2 split-operand chains "
-                     "on the f16 MFMA (3 piece products each) and frac is then a float32-equivalent rate, not the occupancy of one pipe")
+                implementation=("k_train_chains + k_train_outer + k_train_reduce (two kernels, 5 KB of scratch per sample each way)" if pair else
+                                "k_train_coop + k_train_coop_reduce (one cooperative kernel, operands exchanged and transposed in LDS, no scratch in HBM)"),
+                scratch_bytes_per_sample=(2 * 4.0 * 40960 / 32 if pair else 0.0), algorithmic_input_bytes_per_sample=4.0 * (n + 2),
+                hbm_bytes_per_sample_by_counters=traffic, arithmetic=ARITHMETIC,
+                note="achieved = ALGORITHMIC float32 flops per second against the f32 MFMA peak; in the default arithmetic (f32) every product runs on "
+                     "the f32 MFMA; with --arithmetic f16x2 the two-kernel form runs its eight wide chain products as f16x2 split-operand chains on the "
+                     "f16 MFMA (3 piece products each) and frac is then a float32-equivalent rate, not the occupancy of one pipe; "
+                     "hbm_bytes_per_sample_by_counters is static (profiles/r03_train_coop_summary.json: 2 x FETCH_SIZE + WRITE_SIZE at B = 2^20)")
 
 
 def optimiser_step(world, dist, system="cartpole", total=256):
