@@ -334,7 +334,7 @@ int hjbx_vhjb_rollout_f32(const hjbx_system* sys, const hjbx_task* task, const h
  * :284) -- the buffer a data-parallel step all-reduces once.  hjb_loss is a function of dV/dx, so its gradient is a second-order
  * reverse sweep; both are evaluated in closed form (no autograd graph).  `mode` = hjbx_residual_mode.  Deterministic: no float atomics,
  * fixed summation order (the order depends on B and the device's CU count only).  ReLU, tanh and (state dimension <= 4) sin networks with features [128,128,64]
- * (HJBX_EUNSUPPORTED otherwise: the PyTorch autograd path remains).  workspace: hjbx_value_loss_grad_workspace_bytes(B) bytes (it depends on
+ * (HJBX_EUNSUPPORTED otherwise: the PyTorch autograd path remains); W1, W2, W3 16-byte aligned.  workspace: hjbx_value_loss_grad_workspace_bytes(B) bytes (it depends on
  * HJBX_OPT_MLP_ARITHMETIC / HJBX_OPT_TRAIN_KERNEL: ask again after changing them), 256-byte aligned, need not be initialised. */
 size_t hjbx_value_loss_grad_workspace_bytes(int64_t B);
 int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,

@@ -1,9 +1,9 @@
 // hjbx_mlp.hip -- ValueFunctionApproximator forward + input gradient (reference controller/vhjb.py:17-60
 // and get_v_gradient :201-202) fused into one gfx950 kernel on the matrix cores: this file holds the two kernels and the float32-MFMA
 // arithmetic described below; the same kernels instantiate the 16-bit split-operand arithmetics of hjbx_mlp_x3.hpp (bf16 x 3) and
-// hjbx_mlp_h2.hpp (f16 x 2, the library default for ReLU networks) through the AR template parameter.
+// hjbx_mlp_h2.hpp (f16 x 2; both opt-in, HJBX_OPT_MLP_ARITHMETIC) through the AR template parameter.
 //
-//   e = wrap(x - xf); z = (e - mean)/std; h1 = act(z W1); h2 = act(h1 W2); y = h2 W3        (act = relu | tanh)
+//   e = wrap(x - xf); z = (e - mean)/std; h1 = act(z W1); h2 = act(h1 W2); y = h2 W3        (act = relu | tanh | sin)
 //   V = |y|^2 + eps_s |e|^2
 //   dV/dx = ((((2y) W3') . act'(h2)) W2' . act'(h1)) W1' / std + 2 eps_s e
 //

@@ -5,8 +5,10 @@
 //   x w  =  hi hi + hi lo + lo hi  +  [lo lo, r w, x r': dropped, together <= 3 x 2^-22 |x w|, typically ~2^-23]
 //
 // Half the matrix-pipe work of the bf16x3 scheme (hjbx_mlp_x3.hpp) and two thirds of its LDS image, at ~4x the rounding of a float32
-// product in the worst case (measured: indistinguishable) -- 14x inside the 1e-5 tolerance of the path.  The library's DEFAULT arithmetic
-// (HJBX_OPT_MLP_ARITHMETIC = 2); every per-element parity test runs in it, in bf16x3 and in the f32 MFMA mode against the same bounds.
+// product in the worst case (measured: indistinguishable) -- 14x inside the 1e-5 tolerance of the path.  OPT-IN (HJBX_OPT_MLP_ARITHMETIC = 2;
+// the library default is the f32 MFMA = the reference's arithmetic; this mode was the default for the second half of round 2); every
+// per-element parity test runs in it, in bf16x3 and in the f32 MFMA mode against the same bounds, and a device property test holds it to
+// |delta| <= c 2^-22 (sum of the element's |terms|) + 2^-39 (scaling maximum) against mode 0 on the same inputs.
 //
 // float16 has a 5-bit exponent, so every operand is scaled by a power of two first (exact):
 //  * weights: one exponent per matrix, chosen when the LDS image is built, so that max |w| 2^kw is in [2^12, 2^13);

@@ -1,5 +1,5 @@
 // hjbx_train.hip -- the parameter gradient of the value-learning step (reference controller/vhjb.py:227-253, 282-284) on the
-// matrix cores (chains: f16x2 split-operand products by default, f32 MFMA on request; outer products: f32 MFMA): d(sum_b hjb_loss_b)/dW and d(sum_b termination_loss_b)/dW for W1, W2, W3 of the 3-layer value network, plus the loss
+// matrix cores (chains: f32 MFMA, or f16x2 split-operand products with HJBX_OPT_MLP_ARITHMETIC = 2; outer products: f32 MFMA; since round 3 this two-kernel form is opt-in, hjbx_train_coop.hip is the default): d(sum_b hjb_loss_b)/dW and d(sum_b termination_loss_b)/dW for W1, W2, W3 of the 3-layer value network, plus the loss
 // sums and the two counts, for a batch of B samples (x, cost, done).  hjb_loss depends on the weights through dV/dx, so its
 // parameter gradient is a second-order reverse sweep ("double back-prop": jax.grad of a function of jax.grad in the reference).
 //
@@ -651,6 +651,8 @@ extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task*
     const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
     if ((reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x must be aligned to its row vector width and workspace to 256 bytes");
+    if ((reinterpret_cast<uintptr_t>(mlp->W1) | reinterpret_cast<uintptr_t>(mlp->W2) | reinterpret_cast<uintptr_t>(mlp->W3)) & 15u)
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: the weight matrices must be 16-byte aligned");
     for (int k = 0; k < sys->n; ++k)
         if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: normalization_std[%d] is zero", k);
     if (!use_two_kernels(mlp->activation)) return hjbx_train_coop(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream);

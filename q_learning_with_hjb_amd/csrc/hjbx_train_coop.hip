@@ -194,9 +194,16 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     __shared__ Limits<float, M> lim_s;
     const int tid = threadIdx.x;
     if (tid == 0) { sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k; }
-    for (int idx = tid; idx < N * kH1; idx += 256) L.W1[(idx / kH1) * kLD1 + (idx % kH1)] = W1g[idx];
-    for (int idx = tid; idx < kH1 * kH2; idx += 256) L.W2[(idx / kH2) * kLD2 + (idx % kH2)] = W2g[idx];
-    for (int idx = tid; idx < kH2 * kH3; idx += 256) L.W3[(idx / kH3) * kLD3 + (idx % kH3)] = W3g[idx];
+    {   // weights -> LDS (odd row strides), 16 bytes per global load: at the reference's minibatch (8 tiles) this fill is on the latency path
+        static_assert(kH1 % 4 == 0 && kH2 % 4 == 0 && kH3 % 4 == 0, "");
+        const float4* W1v = reinterpret_cast<const float4*>(W1g);
+        const float4* W2v = reinterpret_cast<const float4*>(W2g);
+        const float4* W3v = reinterpret_cast<const float4*>(W3g);
+        auto put4 = [](float* dst, const float4& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; };
+        for (int idx = tid; idx < N * kH1 / 4; idx += 256) put4(&L.W1[(idx / (kH1 / 4)) * kLD1 + 4 * (idx % (kH1 / 4))], W1v[idx]);
+        for (int idx = tid; idx < kH1 * kH2 / 4; idx += 256) put4(&L.W2[(idx / (kH2 / 4)) * kLD2 + 4 * (idx % (kH2 / 4))], W2v[idx]);
+        for (int idx = tid; idx < kH2 * kH3 / 4; idx += 256) put4(&L.W3[(idx / (kH3 / 4)) * kLD3 + 4 * (idx % (kH3 / 4))], W3v[idx]);
+    }
     if (tid < 32) L.zeros[tid] = 0.f;
     if (tid < 128) L.sums[tid >> 5][tid & 31] = 0.0;
     for (int idx = tid; idx < kExFloats; idx += 256) L.E[2][idx] = 0.f;   // (the first tile's chain 2 reads "the previous tile's a1b" from here)
