@@ -605,9 +605,20 @@ def main():
             torch.cuda.empty_cache()
             sec.append(param_gradient_kernels("nearhover", 1 << 20))
             torch.cuda.empty_cache()
-        sec_strong = strong_scaling_line(world, rank, dist, barrier)   # configs[3]: 2^18 planar quadrotors IN TOTAL, sharded over the ranks
-        sec_opt = optimiser_step(world, dist)                  # every rank takes part (all-reduce inside for G > 1)
-        sec_big = optimiser_step(world, dist, "nearhover", (1 << 20) * world)     # configs[4]: the sharded full-batch learning step
+        def guarded(name, fn):
+            """A secondary measurement must not cost the run its JSON line: an exception becomes an entry of its own.  (Every rank takes part
+            in these three; an error raised on every rank alike -- a shape, a missing kernel -- is skipped by all of them together.)"""
+            try:
+                return fn()
+            except Exception as exc:  # noqa: BLE001
+                return dict(name=name, error=f"{type(exc).__name__}: {exc}")
+
+        # configs[3]: 2^18 planar quadrotors IN TOTAL, sharded over the ranks
+        sec_strong = guarded("strong scaling: fused vhjb rollout, quad2d", lambda: strong_scaling_line(world, rank, dist, barrier))
+        # every rank takes part (all-reduce inside for G > 1)
+        sec_opt = guarded("params_update (cartpole, 256 samples in total)", lambda: optimiser_step(world, dist))
+        # configs[4]: the sharded full-batch learning step
+        sec_big = guarded("params_update (nearhover, 2^20 samples per GPU)", lambda: optimiser_step(world, dist, "nearhover", (1 << 20) * world))
         if rank == 0:
             sec += [sec_strong, sec_opt, sec_big]
             out["secondary"] = sec
