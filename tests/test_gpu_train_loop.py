@@ -208,3 +208,37 @@ def test_controllers_in_sequence_with_an_eager_garbage_collector():
     finally:
         gc.set_threshold(*old)
     torch.cuda.synchronize()
+
+
+def test_fit_phase_entry_points_refuse_bad_arguments():
+    """hjbx_replay_gather_f32 / hjbx_mix_adam_f32 / hjbx_mix_gradients_f32: HJBX_EINVAL (ValueError) instead of a launch for NULL buffers, a state
+    dimension beyond HJBX_MAX_N, a regularisation output without its table, bad Adam hyper-parameters."""
+    import ctypes as C
+    from q_learning_with_hjb_amd import _abi, _ops
+    L = _abi.lib()
+    dev = torch.device("cuda")
+    bx, bc, bd = torch.zeros((8, 4), device=dev), torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    perm, step = torch.arange(8, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    xs, cs, ds, reg = torch.zeros((4, 4), device=dev), torch.zeros(4, device=dev), torch.zeros(4, device=dev), torch.zeros((), device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ok = L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 4, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), None, None)
+    assert ok == 0
+    assert L.hjbx_replay_gather_f32(None, p(bc), p(bd), 4, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 11, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 4, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), p(reg), None) == _abi.EINVAL   # reg_out without reg_table
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 4, p(perm), p(step), None, 0, p(xs), p(cs), p(ds), None, None) == 0               # empty minibatch: nothing to do
+    flat = torch.ones(2 * 6 + 4, device=dev)
+    w = [torch.zeros((1, 2), device=dev), torch.zeros((1, 2), device=dev), torch.zeros((1, 2), device=dev)]
+    m, v = [torch.zeros_like(t) for t in w], [torch.zeros_like(t) for t in w]
+    steps, ticket = [torch.zeros((), device=dev) for _ in w], torch.zeros(1, dtype=torch.int32, device=dev)
+    _ops.mix_adam(flat, 0.1, 1e-7, w, m, v, steps, ticket, 1e-3, 0.9, 0.999, 1e-8)
+    assert all(float(k) == 1.0 for k in steps) and int(ticket) == 0
+    for bad in (dict(lr=0.0), dict(beta1=1.0), dict(beta2=-0.1), dict(adam_eps=-1.0)):
+        kw = dict(lr=1e-3, beta1=0.9, beta2=0.999, adam_eps=1e-8)
+        kw.update(bad)
+        with pytest.raises(ValueError):
+            _ops.mix_adam(flat, 0.1, 1e-7, w, m, v, steps, ticket, kw["lr"], kw["beta1"], kw["beta2"], kw["adam_eps"])
+    assert all(float(k) == 1.0 for k in steps)                    # nothing ran
+    with pytest.raises(ValueError):
+        _ops.mix_adam(flat[:-1].contiguous(), 0.1, 1e-7, w, m, v, steps, ticket, 1e-3, 0.9, 0.999, 1e-8)   # flat does not hold 2 P + 4 floats
+    assert L.hjbx_mix_gradients_f32(None, 6, None, 0.0, 1e-7, p(flat), None, None, None, None) == _abi.EINVAL
