@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 108 /* major*100 + minor */
+#define HJBX_VERSION 109 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -370,10 +370,13 @@ int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, doubl
  * (vhjb.py:151-154, 314; utils/utils.py:7-14) for a device-resident replay buffer (buf_x (capacity, n), buf_cost, buf_done (capacity,)):
  *   xs[s] = buf_x[perm[k * batch + s]] (likewise costs, dones), s = 0..batch-1, with k = step_dev[0] read ON THE DEVICE (NULL: k = 0), and
  *   reg_out[0] = reg_table[k] when reg_out is non-NULL (the regularisation weight of update k of the epoch, vhjb.py:323-324).
- * perm: int32 row indices (one random permutation of the buffer per epoch).  With step_dev = the counter hjbx_mix_gradients_f32 increments, a
- * captured hipGraph of gather -> hjbx_value_loss_grad_f32 -> mix -> Adam replays with no host-side work between two updates. */
-int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost, const float* buf_done, int n, const int32_t* perm, const int32_t* step_dev,
-                           const float* reg_table, int64_t batch, float* xs, float* costs, float* dones, float* reg_out, void* stream);
+ * perm: perm_len int32 row indices < capacity (one random permutation of the buffer per epoch); reg_table: table_len floats.  A counter
+ * beyond the permutation or the table, or an index outside the buffer, gathers nothing (no out-of-bounds access) and sets reg_out to NaN.
+ * With step_dev = the counter hjbx_mix_gradients_f32 / hjbx_mix_adam_f32 increment, a captured hipGraph of gather ->
+ * hjbx_value_loss_grad_f32 -> mix + Adam replays with no host-side work between two updates. */
+int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost, const float* buf_done, int64_t capacity, int n, const int32_t* perm,
+                           int64_t perm_len, const int32_t* step_dev, const float* reg_table, int64_t table_len, int64_t batch, float* xs,
+                           float* costs, float* dones, float* reg_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -265,7 +265,7 @@ def lib() -> C.CDLL:
         L.hjbx_mix_adam_f32.restype = C.c_int
         L.hjbx_mix_adam_f32.argtypes = [_VP, _VP, _DBL, _DBL, C.POINTER(HjbxAdamState), _VP, _VP, _VP, _VP]
         L.hjbx_replay_gather_f32.restype = C.c_int
-        L.hjbx_replay_gather_f32.argtypes = [_VP, _VP, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP]
+        L.hjbx_replay_gather_f32.argtypes = [_VP, _VP, _VP, _I64, _I32, _VP, _I64, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP, _VP]
         for name, sig in _typed_signatures().items():
             for sfx in ("f32", "f64"):
                 fn = getattr(L, f"hjbx_{name}_{sfx}")

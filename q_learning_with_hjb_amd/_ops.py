@@ -359,5 +359,5 @@ def replay_gather(buf_x, buf_cost, buf_done, perm, step_counter, reg_table, xs, 
     _chk(dones, "dones", (batch,), torch.float32)
     _chk(reg_out, "reg_out", (), torch.float32)
     _chk(reg_table, "reg_table", (reg_table.shape[0],), torch.float32)
-    check(lib().hjbx_replay_gather_f32(_p(buf_x), _p(buf_cost), _p(buf_done), int(n), _p(perm), _p(step_counter), _p(reg_table), int(batch), _p(xs), _p(costs),
-                                       _p(dones), _p(reg_out), _stream()))
+    check(lib().hjbx_replay_gather_f32(_p(buf_x), _p(buf_cost), _p(buf_done), int(buf_x.shape[0]), int(n), _p(perm), int(perm.shape[0]), _p(step_counter),
+                                       _p(reg_table), int(reg_table.shape[0]), int(batch), _p(xs), _p(costs), _p(dones), _p(reg_out), _stream()))

@@ -121,7 +121,10 @@ extern "C" int hjbx_system_create_from_source(int user_kind, const char* device_
     for (int j = 0; j < m; ++j)
         if (!(umin[j] <= umax[j])) return hjbx_set_error(HJBX_EINVAL, "umin[%d] > umax[%d]", j, j);
     const Rtc& R = rtc();
-    if (!R.ok) return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_system_create_from_source: libhiprtc.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (!R.ok) {
+        const char* why = dlerror();       // (one call: dlerror clears the message it returns)
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_system_create_from_source: libhiprtc.so could not be loaded (%s)", why ? why : "symbols missing");
+    }
 
     const char* headers[] = {hjbx_src_systems, hjbx_src_stream, hjbx_src_user, device_source, kStubRuntime, kStubStdint};
     const char* names[] = {"hjbx_systems.hpp", "hjbx_stream_kernels.hpp", "hjbx_user_kernels.hpp", "hjbx_user_snippet.hpp", "hip/hip_runtime.h", "stdint.h"};

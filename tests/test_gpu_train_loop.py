@@ -221,12 +221,27 @@ def test_fit_phase_entry_points_refuse_bad_arguments():
     perm, step = torch.arange(8, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
     xs, cs, ds, reg = torch.zeros((4, 4), device=dev), torch.zeros(4, device=dev), torch.zeros(4, device=dev), torch.zeros((), device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
-    ok = L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 4, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), None, None)
+    ok = L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 8, 4, p(perm), 8, p(step), None, 0, 4, p(xs), p(cs), p(ds), None, None)
     assert ok == 0
-    assert L.hjbx_replay_gather_f32(None, p(bc), p(bd), 4, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL
-    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 11, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL
-    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 4, p(perm), p(step), None, 4, p(xs), p(cs), p(ds), p(reg), None) == _abi.EINVAL   # reg_out without reg_table
-    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 4, p(perm), p(step), None, 0, p(xs), p(cs), p(ds), None, None) == 0               # empty minibatch: nothing to do
+    assert L.hjbx_replay_gather_f32(None, p(bc), p(bd), 8, 4, p(perm), 8, p(step), None, 0, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 8, 11, p(perm), 8, p(step), None, 0, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 8, 4, p(perm), 8, p(step), None, 0, 4, p(xs), p(cs), p(ds), p(reg), None) == _abi.EINVAL   # reg_out without reg_table
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 8, 4, p(perm), 8, p(step), None, 0, 0, p(xs), p(cs), p(ds), None, None) == 0               # empty minibatch: nothing to do
+    assert L.hjbx_replay_gather_f32(p(bx), p(bc), p(bd), 8, 4, p(perm), 3, p(step), None, 0, 4, p(xs), p(cs), p(ds), None, None) == _abi.EINVAL     # permutation shorter than a minibatch
+    # a counter that has run past the epoch gathers nothing and poisons the regularisation weight instead of reading out of bounds
+    table = torch.ones(2, device=dev)
+    bx.copy_(torch.arange(32, device=dev).reshape(8, 4).float())
+    xs.fill_(-1.0)
+    step.fill_(2)                                                 # minibatch 2 of 4 rows needs perm[8:12]: beyond the 8 entries
+    _ops.replay_gather(bx, bc, bd, perm, step, table, xs, cs, ds, reg)
+    assert torch.isnan(reg) and float(xs.min()) == -1.0 and float(xs.max()) == -1.0
+    step.fill_(1)
+    _ops.replay_gather(bx, bc, bd, perm, step, table, xs, cs, ds, reg)
+    assert float(reg) == 1.0 and torch.equal(xs, bx[4:8])
+    perm[5] = 99                                                  # an index outside the buffer: that row is skipped, nothing is read
+    xs.fill_(-1.0)
+    _ops.replay_gather(bx, bc, bd, perm, step, table, xs, cs, ds, reg)
+    assert float(xs[1].max()) == -1.0 and torch.equal(xs[0], bx[4]) and torch.equal(xs[2:], bx[6:8])
     flat = torch.ones(2 * 6 + 4, device=dev)
     w = [torch.zeros((1, 2), device=dev), torch.zeros((1, 2), device=dev), torch.zeros((1, 2), device=dev)]
     m, v = [torch.zeros_like(t) for t in w], [torch.zeros_like(t) for t in w]
