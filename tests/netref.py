@@ -102,3 +102,22 @@ class NetRef:
         tg = (d1 @ A1.T) / np.abs(self.std) + 2.0 * self.eps * np.abs(fw["e"])
         tv = 2.0 * (np.abs(fw["y"]) * ty).sum(1) + self.eps * (fw["e"] ** 2).sum(1)
         return tv, tg, ty
+
+
+def smooth_term_scales(W, mean, std, eps_scalar, e, activation):
+    """Per-element term scales of V and dV/dx for a network with a smooth activation ("tanh", "sin"), float64: the sums of the MAGNITUDES of the
+    terms that make up each y_j, V and each component of dV/dx along the actual activations and activation derivatives (the analogue of
+    NetRef's ReLU term scales).  W: float64 (in, out) matrices; e: wrapped error coordinates.  -> (scale of V (B,), scale of dV/dx (B, n))"""
+    W1, W2, W3 = (np.asarray(w, np.float64) for w in W)
+    f, df = {"tanh": (np.tanh, lambda a: 1.0 - np.tanh(a) ** 2), "sin": (np.sin, np.cos)}[activation]
+    std = np.abs(np.asarray(std, np.float64)).reshape(1, -1)
+    z = (e - np.asarray(mean, np.float64).reshape(1, -1)) / std
+    a1 = z @ W1
+    h1, s1 = f(a1), np.abs(df(a1))
+    a2 = h1 @ W2
+    h2, s2 = f(a2), np.abs(df(a2))
+    y = h2 @ W3
+    t_y = np.abs(h2) @ np.abs(W3)
+    sV = (2.0 * np.abs(y) * t_y).sum(1) + (y * y).sum(1) + eps_scalar * (e * e).sum(1)
+    G = (((((2.0 * t_y) @ np.abs(W3).T) * s2) @ np.abs(W2).T) * s1) @ np.abs(W1).T / std + 2.0 * eps_scalar * np.abs(e)
+    return sV, G

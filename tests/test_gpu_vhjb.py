@@ -623,13 +623,22 @@ def test_tanh_network_fused_kernels_vs_oracle_and_torch(activation, name, B):
     x = states_near_target(d, ctl, B, 2, 1.5)
     V, g = vf.fused_value_grad(x)
     mlp, W = oracle_mlp(ctl)
-    oV, og = O.value_grad(O.System.from_dynamics(d), mlp, *W, x.cpu().numpy().astype(np.float64))
+    s = O.System.from_dynamics(d)
+    xn = x.cpu().numpy().astype(np.float64)
+    oV, og = O.value_grad(s, mlp, *W, xn)
+    # the yardstick of the float32 parity tests: the kernel's per-element errors against the f64 oracle must stay within 2x those
+    # of the oracle's own float build (libm tanhf / sinf / cosf) on the same inputs, relative to per-element term scales
+    cV, cg = O.value_grad(s, mlp, *W, xn, dtype=np.float32)
+    from netref import smooth_term_scales
+    from parity_util import assert_within_cpu_yardstick
+    e = O.wrap(s, xn - np.asarray(vf._np["xf"], np.float64)[None, :])
+    sV, G = smooth_term_scales(W, vf._np["mean"], vf._np["std"], vf.epsilon_scalar, e, activation)
+    assert_within_cpu_yardstick(f"{activation} {name} V", V.cpu().numpy(), cV, oV, sV)
+    assert_within_cpu_yardstick(f"{activation} {name} dV/dx", g.cpu().numpy(), cg, og, G)
     sv, sg = np.abs(oV).max(), np.abs(og).max()
-    assert np.abs(V.cpu().numpy() - oV).max() <= 3e-5 * sv, np.abs(V.cpu().numpy() - oV).max() / sv
-    assert np.abs(g.cpu().numpy() - og).max() <= 3e-5 * sg, np.abs(g.cpu().numpy() - og).max() / sg
     with torch.no_grad():
         tV, tg = vf.value_and_grad(x)
-    assert float((tV - V).abs().max()) <= 3e-5 * sv and float((tg - g).abs().max()) <= 3e-5 * sg
+    assert float((tV - V).abs().max()) <= 3e-5 * sv and float((tg - g).abs().max()) <= 3e-5 * sg       # (the PyTorch graph: another float32 evaluation)
     # fused rollout == stepwise, and both follow the oracle's loop
     T = 10
     x0 = states_near_target(d, ctl, B, 8, 1.03)
