@@ -36,13 +36,15 @@ def _batch(d, ctl, B, seed, frac=0.6, p_done=0.3):
     return xs, dones, costs
 
 
-def _reference_sums_f64(name, ctl32, xs, dones, costs, mode=_abi.RESIDUAL_NORMALISED):
-    """float64 autograd double back-prop of the loss SUMS on the float32 weights -> (g_h list, g_t list, scalars)"""
-    d64, ctl64 = controller(name, torch.float64, residual_mode=mode, activation=ctl32.value_function_approximator.activation)
+def _reference_sums_f64(name, ctl32, xs, dones, costs, mode=_abi.RESIDUAL_NORMALISED, dtype=torch.float64):
+    """float64 autograd double back-prop of the loss SUMS on the float32 weights -> (g_h list, g_t list, scalars).  dtype=torch.float32: the same
+    graph evaluated in float32 by PyTorch (matmuls + the library's float32 residual kernels) -- the yardstick a float32 kernel is held to."""
+    kw = dict(fused_param_grad=False) if dtype == torch.float32 else {}
+    d64, ctl64 = controller(name, dtype, residual_mode=mode, activation=ctl32.value_function_approximator.activation, **kw)
     with torch.no_grad():
         for w64, w32 in zip(ctl64.value_function_approximator.weights, ctl32.value_function_approximator.weights):
-            w64.copy_(w32.double())
-    x64, dn64, c64 = xs.double(), dones.double(), costs.double()
+            w64.copy_(w32.to(dtype))
+    x64, dn64, c64 = xs.to(dtype), dones.to(dtype), costs.to(dtype)
     params = list(ctl64.value_function_approximator.parameters())
     if mode == _abi.RESIDUAL_NORMALISED:
         h, t = _autograd_losses(ctl64, x64, dn64, c64)          # means: multiply the normalisers back
@@ -96,6 +98,25 @@ def test_value_loss_grad_vs_f64_autograd(name, B, impl):
             err = np.abs(a - b)
             assert err.max() <= 1e-4 * scale, f"{label} dW{k + 1}: max err {err.max():.3e} vs scale {scale:.3e} (rel {err.max() / scale:.2e})"
             assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), f"{label} dW{k + 1}: Frobenius rel {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
+    # printed, not asserted: the kernel's Frobenius error per matrix over that of PyTorch's float32 autograd (rocBLAS matmuls + the library's
+    # float32 residual kernels) against the same float64 reference.  For a ReLU network the statistic is heavy-tailed -- one sample whose unit
+    # sits at a kink is taken on different sides by different float32 evaluations and then dominates either error (measured 0.4 - 0.9
+    # typically, outliers 0.2 - 8 in both directions), and |r| at r = 0 and the clip of u are kinks of the loss itself -- so for this row the
+    # ratio is reported and the asserted bounds stay the analytic ones above (1e-4 of each matrix's scale; measured errors: 1e-6 - 4e-6).
+    print(f"    {name} B={B}: kernel / PyTorch-float32 Frobenius error per matrix: " + " ".join(f"{r:.2f}" for r in _yardstick_ratios(name, ctl, xs, dones, costs, gh, gt, rh, rt)))
+
+
+def _yardstick_ratios(name, ctl, xs, dones, costs, gh, gt, rh, rt, mode=_abi.RESIDUAL_NORMALISED):
+    """kernel Frobenius error / PyTorch-float32-autograd Frobenius error, per gradient matrix, both against the float64 reference"""
+    th, tt, _ = _reference_sums_f64(name, ctl, xs, dones, costs, mode=mode, dtype=torch.float32)
+    ratios = []
+    for got, want, t32 in ((gh, rh, th), (gt, rt, tt)):
+        for a, b, c in zip(got, want, t32):
+            b, c = b.cpu().numpy().astype(np.float64), c.cpu().numpy().astype(np.float64)
+            if np.abs(b).max() == 0:
+                continue
+            ratios.append(np.linalg.norm(a - b) / max(np.linalg.norm(c - b), 2.0 ** -23 * np.linalg.norm(b)))
+    return ratios
 
 
 @pytest.mark.parametrize("name", ["cartpole", "quad2d"])
@@ -217,6 +238,10 @@ def test_value_loss_grad_tanh_network_vs_f64_autograd(activation, name, B, mode)
             err = np.abs(a - b)
             assert err.max() <= 1e-4 * scale, f"{activation} {label} dW{k + 1}: max err {err.max():.3e} vs scale {scale:.3e} (rel {err.max() / scale:.2e})"
             assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), f"{activation} {label} dW{k + 1}: Frobenius rel {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
+    # (printed like in test_value_loss_grad_vs_f64_autograd: the loss itself has kinks -- |r| at r = 0, the clip of u -- so single samples can
+    # dominate either float32 evaluation's error with a smooth activation too: measured 0.1 - 1.2 typically, 3.5 once)
+    ratios = _yardstick_ratios(name, ctl, xs, dones, costs, gh, gt, rh, rt, mode=mode)
+    print(f"    {activation} {name} B={B}: kernel / PyTorch-float32 Frobenius error per matrix: " + " ".join(f"{r:.2f}" for r in ratios))
     # the second-order terms are really there: dropping them (= treating tanh like a piecewise-linear unit) would be far outside the bound
     if B == 256 and mode == _abi.RESIDUAL_NORMALISED:
         assert np.abs(rh[1].cpu().numpy()).max() > 0
