@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../.."
 C=q_learning_with_hjb_amd/csrc
 mkdir -p build/dev
-OBJS="$C/hjbx_kernels.o $C/hjbx_mlp_relu.o $C/hjbx_mlp_tanh.o $C/hjbx_mlp_x3.o $C/hjbx_mlp_h2.o $C/hjbx_train.o $C/hjbx_fit.o $C/hjbx_user.o"
+OBJS="$C/hjbx_kernels.o $C/hjbx_mlp_relu.o $C/hjbx_mlp_tanh.o $C/hjbx_mlp_x3.o $C/hjbx_mlp_h2.o $C/hjbx_mlp_sin.o $C/hjbx_train.o $C/hjbx_fit.o $C/hjbx_user.o"
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -fPIC -fno-slp-vectorize -DHJBX_TRAIN_DEV $flags -c $C/hjbx_train_coop.hip -o build/dev/coop_$tag.o &
