@@ -137,6 +137,9 @@ def test_device_driven_fit_phase_equals_the_per_minibatch_loop(name, activation,
     on the device (VHJBController._fit_epoch_graphed: hjbx_replay_gather_f32 + hjbx_mix_gradients_f32's accumulators) against the plain
     loop `for minibatch: params_update(...)` (vhjb.py:314-324) on eager launches: same seeds -> same permutations -> the same kernels on
     the same inputs, so weights, Adam state, counters and the returned loss lists agree to rounding of the float32 loss accumulation."""
+    import os
+    if os.environ.get("HJBX_FUSED_PARAM_GRAD", "1") == "0":
+        pytest.skip("HJBX_FUSED_PARAM_GRAD=0: the device-driven fit phase belongs to the fused parameter gradient")
     kw = dict(epochs=3, num_of_trajectories_per_epoch=5, maximum_step=40, batch_size=batch, maximum_buffer_size=700,
               regularization_warmup_steps_per_cycle=4, regularization_total_steps_per_cycle=9, regularization_num_of_cycles=2, regularization_peak_value=1e-2)
     outs, ctls = [], []
@@ -150,13 +153,21 @@ def test_device_driven_fit_phase_equals_the_per_minibatch_loop(name, activation,
     assert a._fit_graph is not None and a._graphed_update is None and b._fit_graph is None      # the device-driven path did run
     assert a.update_counter == b.update_counter > 3 and a.regularization == b.regularization
     assert len(a.replay_buffer) == len(b.replay_buffer)
+    # bit-equal when the Adam step is the library's (the default: the same kernels on both sides); with HJBX_FUSED_ADAM=0 the graph replays
+    # torch.optim.Adam's capturable implementation and the loop its non-capturable one, which round differently
+    # (there: the typical entry agrees to 1e-6, and an entry whose gradient is of the order of Adam's eps may take its first +-lr steps in
+    # another direction)
+    lr = float(a.optimizer.param_groups[0]["lr"])
+    native = a._native_adam and b._native_adam
+    same = (lambda x, y: torch.equal(x, y)) if native else \
+        (lambda x, y: float((x - y).abs().median()) <= 1e-6 + 1e-5 * float(y.abs().median()) and float((x - y).abs().max()) <= 2 * lr * a.update_counter)
     for wa, wb in zip(a.value_function_approximator.weights, b.value_function_approximator.weights):
-        assert torch.equal(wa, wb)
+        assert same(wa, wb)
     for pa, pb in zip(a.value_function_approximator.parameters(), b.value_function_approximator.parameters()):
         sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
-        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
+        assert same(sa["exp_avg"], sb["exp_avg"]) and same(sa["exp_avg_sq"], sb["exp_avg_sq"]) and float(sa["step"]) == float(sb["step"])
     for la, lb in zip(outs[0], outs[1]):
-        np.testing.assert_allclose(la, lb, rtol=2e-6)
+        np.testing.assert_allclose(la, lb, rtol=2e-6 if native else 1e-2)
 
 
 def test_replay_gather_reads_its_minibatch_number_from_the_device():
@@ -201,7 +212,7 @@ def test_controllers_in_sequence_with_an_eager_garbage_collector():
             holder = [ctl]
             holder.append(holder)                      # a reference cycle around the controller: only the cyclic collector can free it
             ctl.train()
-            assert ctl._fit_graph is not None
+            assert ctl._fit_graph is not None or not ctl.fused_param_grad
             counters.append(ctl.update_counter)
             del ctl, holder
         assert all(c > 0 for c in counters)
