@@ -601,6 +601,15 @@ def main():
                                 live_fraction=lv / (w2["B"] * 40)))
                 del w2
                 torch.cuda.empty_cache()
+            for act in ("tanh", "sin"):      # the notebooks' value networks (cartpole_balancing.ipynb cell 6; double_integrator_optimal_time.ipynb cell 5)
+                w2 = make_workload("cartpole", "euler", act, 1 << 20, 1)
+                ws, ls, lv = time_fused(w2, 40, 10, 3, 0, lambda: torch.cuda.synchronize(), prewarm=0.0)
+                rf = mfma_roofline(w2, ls, w2["B"])
+                sec.append(dict(name=f"fused vhjb rollout: cartpole euler B=2^20, {act} value network", value=lv / float(np.median(ws)), unit="env-steps/s",
+                                ms_per_step=float(np.median(ws)) / 40 * 1e3, achieved=rf["achieved"], peak=rf["peak"], frac=rf["frac"], bound="mfma",
+                                live_fraction=lv / (w2["B"] * 40)))
+                del w2
+                torch.cuda.empty_cache()
             sec += hbm_entry_points("cartpole")
             torch.cuda.empty_cache()
             sec.append(param_gradient_kernels("nearhover", 1 << 20))
