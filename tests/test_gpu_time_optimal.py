@@ -104,12 +104,13 @@ def test_bang_bang_vhjb_step_vs_oracle(name, prec):
     assert np.allclose(oc[live], d.dt)                                         # unit running cost x dt
 
 
-def test_bang_bang_fused_rollout_equals_stepwise_and_oracle():
-    """The persistent MFMA rollout kernel with the bang-bang law (ReLU value net): bit-identical to value_grad + vhjb_step
-    step by step, done_step equal to the oracle's env-by-env loop on almost every environment."""
+@pytest.mark.parametrize("activation", ["relu", "sin"])
+def test_bang_bang_fused_rollout_equals_stepwise_and_oracle(activation):
+    """The persistent MFMA rollout kernel with the bang-bang law (ReLU value net, and the notebook's own sin network): bit-identical to
+    value_grad + vhjb_step step by step, done_step equal to the oracle's env-by-env loop on almost every environment."""
     d = _double_integrator()
     d.integrator = _abi.ZOH
-    ctl = TimeOptimalVHJBController(d, activation="relu", num_states=1024, seed=3)
+    ctl = TimeOptimalVHJBController(d, activation=activation, num_states=1024, seed=3)
     assert ctl.fused
     vf = ctl.value_function_approximator
     B, T = 1000, 40
@@ -126,7 +127,7 @@ def test_bang_bang_fused_rollout_equals_stepwise_and_oracle():
     assert torch.equal(ds1, ds) and torch.equal(one["traj"], traj) and torch.equal(one["cost"], cost) and torch.equal(one["done"], done)
     assert (ds[:10] == 0).all()
     W = [w.detach().cpu().numpy().astype(np.float64) for w in vf.weights]
-    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar)
+    mlp = O.make_mlp(vf.features, vf._np["mean"], vf._np["std"], vf._np["xf"], vf.epsilon_scalar, activation=activation)
     ref = O.vhjb_rollout(O.System.from_dynamics(d), ctl._task, mlp, *W, x0.cpu().numpy().astype(np.float64), T, integrator=_abi.ZOH)
     assert (ds.cpu().numpy() == ref["done_step"]).mean() > 0.9              # bang-bang: one fp32 sign flip shifts an arrival
     # time_to_target wraps exactly this
