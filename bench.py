@@ -398,7 +398,7 @@ def optimiser_step(world, dist, system="cartpole", total=256):
             ctl._fit_epoch_graphed(per_rank, nbt)               # ends with the read-back of the loss sums: synchronous
             ts.append((time.perf_counter() - t1) / nbt)
         fit = dict(updates_per_epoch=nbt, ms_per_update=float(np.median(ts)) * 1e3, updates_per_s=1.0 / float(np.median(ts)),
-                   what="VHJBController.train's fit phase: one hipGraph replay per update (gather -> parameter gradient -> mix -> Adam), per-epoch "
+                   what="VHJBController.train's fit phase: one hipGraph replay per update (gather -> parameter gradient -> reduce + mix + Adam epilogue), per-epoch "
                         "host work (permutation, schedule table, loss read-back) included")
     return dict(name=f"params_update ({system}, {total} samples in total)", ranks=world, samples_per_rank=per_rank, updates_per_s=R / dt,
                 samples_per_s=R * per_rank * world / dt, ms_per_update=dt / R * 1e3, fit_phase=fit,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 109 /* major*100 + minor */
+#define HJBX_VERSION 110 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -365,6 +365,16 @@ typedef struct hjbx_adam_state {
 } hjbx_adam_state;
 int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses, float* loss_accum,
                       int32_t* step_counter, void* stream);
+
+/* params_update (vhjb.py:255-288) in ONE call for a single process: hjbx_value_loss_grad_f32 followed by hjbx_mix_adam_f32, with the flat
+ * buffer never materialised on the default (cooperative) path -- the reduction of the per-workgroup partial sums, the division by the counts,
+ * the mix, the losses and Adam's update run in one epilogue kernel, i.e. two launches per update.  Arguments as in those two entry points;
+ * adam->param[] must be the network's W1, W2, W3.  workspace: hjbx_value_loss_adam_workspace_bytes(B) bytes, 256-byte aligned, need not be
+ * initialised.  (A data-parallel step needs the flat buffer for its all-reduce: hjbx_value_loss_grad_f32, all-reduce, hjbx_mix_adam_f32.) */
+size_t hjbx_value_loss_adam_workspace_bytes(int64_t B);
+int hjbx_value_loss_adam_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
+                             const float* done, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
+                             float* loss_accum, int32_t* step_counter, void* workspace, int64_t B, void* stream);
 
 /* The minibatch of one update, assembled on the device: DataLoader(batch_size, shuffle=True, drop_last=True) + np_collate of the reference
  * (vhjb.py:151-154, 314; utils/utils.py:7-14) for a device-resident replay buffer (buf_x (capacity, n), buf_cost, buf_done (capacity,)):

@@ -280,16 +280,62 @@ def value_loss_grad(sys, task, mlp_desc, x, cost, done, mode=_abi.RESIDUAL_NORMA
     P = sys.n * mlp_desc.h1 + mlp_desc.h1 * mlp_desc.h2 + mlp_desc.h2 * mlp_desc.h3
     flat = torch.empty((2 * P + 4,), dtype=torch.float32, device=x.device) if out is None else out
     _chk(flat, "out", (2 * P + 4,), torch.float32)
-    need = lib().hjbx_value_loss_grad_workspace_bytes(B)
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _tws.get(key)
-    if ws is None or ws.numel() < need or ws.numel() > 4 * need + (64 << 20):     # grow on demand; give a much larger one back (5 KB per sample)
-        ws = None
-        _tws.pop(key, None)
-        ws = torch.empty((need + 255) // 256 * 256, dtype=torch.uint8, device=x.device)
-        _tws[key] = ws
+    ws = _train_workspace(x.device, lib().hjbx_value_loss_grad_workspace_bytes(B))
     check(lib().hjbx_value_loss_grad_f32(sys.ptr, ref(task), ref(mlp_desc), int(mode), _p(x), _p(cost), _p(done), _p(flat), _p(ws), B, _stream()))
     return flat
+
+
+def _train_workspace(device, need):
+    """The per-(device, stream) scratch of the parameter-gradient entry points: grown on demand, a much larger one given back."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _tws.get(key)
+    if ws is None or ws.numel() < need or ws.numel() > 4 * need + (64 << 20):
+        ws = None
+        _tws.pop(key, None)
+        ws = torch.empty((need + 255) // 256 * 256, dtype=torch.uint8, device=device)
+        _tws[key] = ws
+    return ws
+
+
+def _adam_struct(params, exp_avgs, exp_avg_sqs, steps, ticket, lr, beta1, beta2, adam_eps):
+    st = _abi.HjbxAdamState()
+    for i, (p, m, v, k) in enumerate(zip(params, exp_avgs, exp_avg_sqs, steps)):
+        for t, nm in ((p, "param"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _chk(t, nm, tuple(p.shape), torch.float32)
+        _chk(k, "step", (), torch.float32)
+        st.param[i], st.exp_avg[i], st.exp_avg_sq[i], st.numel[i], st.step[i] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), k.data_ptr()
+    _chk(ticket, "ticket", (1,), torch.int32)
+    st.ticket = ticket.data_ptr()
+    st.lr, st.beta1, st.beta2, st.eps = float(lr), float(beta1), float(beta2), float(adam_eps)
+    return st
+
+
+def _reg_args(regularization):
+    if torch.is_tensor(regularization):
+        _chk(regularization, "regularization", (), torch.float32)
+        return _p(regularization), 0.0
+    return None, float(regularization)
+
+
+def value_loss_adam(sys, task, mlp_desc, x, cost, done, mode, regularization, eps, params, exp_avgs, exp_avg_sqs, steps, ticket, lr, beta1, beta2,
+                    adam_eps, loss_accum=None, step_counter=None):
+    """hjbx_value_loss_adam_f32: params_update in one call (gradient, counts, mix, losses, Adam) for a single process; the flat gradient buffer is
+    not materialised on the default path.  -> losses (3,) = [total, hjb, termination]"""
+    B = x.shape[0]
+    _chk(x, "x", (B, sys.n), torch.float32)
+    _chk(cost, "cost", (B,), torch.float32)
+    _chk(done, "done", (B,), torch.float32)
+    st = _adam_struct(params, exp_avgs, exp_avg_sqs, steps, ticket, lr, beta1, beta2, adam_eps)
+    losses = torch.empty((3,), dtype=torch.float32, device=x.device)
+    reg_dev, reg = _reg_args(regularization)
+    if loss_accum is not None:
+        _chk(loss_accum, "loss_accum", (3,), torch.float32)
+    if step_counter is not None:
+        _chk(step_counter, "step_counter", (1,), torch.int32)
+    ws = _train_workspace(x.device, lib().hjbx_value_loss_adam_workspace_bytes(B))
+    check(lib().hjbx_value_loss_adam_f32(sys.ptr, ref(task), ref(mlp_desc), int(mode), _p(x), _p(cost), _p(done), reg_dev, reg, float(eps), C.byref(st), _p(losses),
+                                         _p(loss_accum), _p(step_counter), _p(ws), B, _stream()))
+    return losses
 
 
 def release_workspaces(stream=None):
@@ -325,21 +371,9 @@ def mix_adam(flat, regularization, eps, params, exp_avgs, exp_avg_sqs, steps, ti
     """hjbx_mix_adam_f32: mix of the two gradients + one Adam step on the three weight matrices, in place, one launch.  -> losses (3,)"""
     P = sum(p.numel() for p in params)
     _chk(flat, "flat", (2 * P + 4,), torch.float32)
-    st = _abi.HjbxAdamState()
-    for i, (p, m, v, k) in enumerate(zip(params, exp_avgs, exp_avg_sqs, steps)):
-        for t, nm in ((p, "param"), (m, "exp_avg"), (v, "exp_avg_sq")):
-            _chk(t, nm, tuple(p.shape), torch.float32)
-        _chk(k, "step", (), torch.float32)
-        st.param[i], st.exp_avg[i], st.exp_avg_sq[i], st.numel[i], st.step[i] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), k.data_ptr()
-    _chk(ticket, "ticket", (1,), torch.int32)
-    st.ticket = ticket.data_ptr()
-    st.lr, st.beta1, st.beta2, st.eps = float(lr), float(beta1), float(beta2), float(adam_eps)
+    st = _adam_struct(params, exp_avgs, exp_avg_sqs, steps, ticket, lr, beta1, beta2, adam_eps)
     losses = torch.empty((3,), dtype=torch.float32, device=flat.device)
-    if torch.is_tensor(regularization):
-        _chk(regularization, "regularization", (), torch.float32)
-        reg_dev, reg = _p(regularization), 0.0
-    else:
-        reg_dev, reg = None, float(regularization)
+    reg_dev, reg = _reg_args(regularization)
     if loss_accum is not None:
         _chk(loss_accum, "loss_accum", (3,), torch.float32)
     if step_counter is not None:

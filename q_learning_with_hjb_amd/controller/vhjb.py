@@ -571,6 +571,15 @@ class VHJBController(Controller):
         if self.fused_param_grad:
             # one C-ABI call: [d sum(hjb)/dW | d sum(termination)/dW | sum hjb, sum termination, #interior, #done] -- exactly the buffer
             # the data-parallel step all-reduces once; then the division by the (global) counts and the mix (vhjb.py:241, 253, 284)
+            if self._native_adam and not self._distributed():
+                # one process: gradient, counts, mix, the three losses and optax.adam's step (vhjb.py:120, 262-263) in ONE C-ABI call of two
+                # launches -- the flat buffer is not even materialised (hjbx_value_loss_adam_f32), on the optimiser's own state tensors
+                m, v, step = self._adam_state(model_params)
+                g = self.optimizer.param_groups[0]
+                losses = _ops.value_loss_adam(self.dynamics.system, self._task, self.value_function_approximator.descriptor(), xs, costs, dones,
+                                              self.residual_mode, regularization, self.epsilon, [p.data for p in model_params], m, v, step,
+                                              self._adam_ticket, g["lr"], g["betas"][0], g["betas"][1], g["eps"], loss_accum, step_counter)
+                return losses[0], losses[1], losses[2]
             flat = self.value_loss_gradient(xs, dones, costs)
             if self._native_adam:
                 # counts, mix, the three losses AND optax.adam's step (vhjb.py:120, 262-263) in one launch, on the optimiser's own state tensors

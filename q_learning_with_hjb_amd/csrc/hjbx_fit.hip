@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "hjbx_internal.hpp"
+#include "hjbx_adam.hpp"
 
 // ---- divide by the counts and mix (vhjb.py:241, 253, 284) --------------------------------------------------------------------------
 // mixed = g_h / (#interior + eps) + reg g_t / (#done + eps); losses = {hjb + reg termination, hjb, termination}.  One launch instead of the
@@ -81,79 +82,33 @@ extern "C" int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost,
 
 // ---- mix + Adam in one launch -------------------------------------------------------------------------------------------------------------
 // optax.adam(lr) of the reference (vhjb.py:120: b1 0.9, b2 0.999, eps 1e-8, eps_root 0) applied to the mixed gradient without materialising it:
-//   g = flat[k] / (#interior + eps) + reg flat[P + k] / (#done + eps)
-//   m <- m + (1 - b1) (g - m);  v <- b2 v + (1 - b2) g^2;  t <- t + 1
-//   w <- w - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps_adam)
+//   g = flat[k] / (#interior + eps) + reg flat[P + k] / (#done + eps), then the update of hjbx_adam.hpp
 // (the form torch's fused Adam evaluates, so the state tensors of a torch.optim.Adam can be handed over as they are).  At the reference's
 // minibatch the update is launch bound: this replaces the mix kernel and Adam's two launches.
-struct AdamArgs {
-    float* w[3]; float* m[3]; float* v[3];
-    float* step[3]; unsigned int* ticket;
-    int64_t end0, end1, P;             // parameter k lives in tensor 0 if k < end0, 1 if k < end1, else 2
-    double lr, b1, b2; float eps;
-};
-
-__global__ __launch_bounds__(256) void k_mix_adam(const float* __restrict__ flat, const float* __restrict__ reg_dev, float reg_host, float eps, AdamArgs a,
-                                                 float* __restrict__ losses, float* __restrict__ loss_accum, int32_t* __restrict__ step_counter) {
+__global__ __launch_bounds__(256) void k_mix_adam(const float* __restrict__ flat, AdamArgs a, MixArgs mx) {
     __shared__ float sc[2];
     const int64_t P = a.P;
-    // every workgroup reads the step count BEFORE the last one to finish (ticket below) writes the incremented value
-    const float t = a.step[0][0] + 1.0f;
-    if (threadIdx.x == 0) {
-        sc[0] = (float)(a.lr / (1.0 - pow(a.b1, (double)t)));
-        sc[1] = (float)sqrt(1.0 - pow(a.b2, (double)t));
-    }
-    __syncthreads();
-    const float reg = reg_dev ? reg_dev[0] : reg_host;
-    const float ih = 1.0f / (flat[2 * P + 2] + eps), it = 1.0f / (flat[2 * P + 3] + eps);
+    const AdamCoef c = adam_coef(a, sc);
+    const float reg = mx.reg_dev ? mx.reg_dev[0] : mx.reg_host;
+    const float ih = 1.0f / (flat[2 * P + 2] + mx.eps), it = 1.0f / (flat[2 * P + 3] + mx.eps);
     const float wt = reg * it;
-    const float step_size = sc[0], c2s = sc[1];
-    const float w1 = (float)(1.0 - a.b1), b2 = (float)a.b2, w2 = (float)(1.0 - a.b2);
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < P; k += (int64_t)gridDim.x * 256) {
         const float g = flat[k] * ih + flat[P + k] * wt;
         const int which = k < a.end0 ? 0 : (k < a.end1 ? 1 : 2);
         const int64_t j = k - (which == 0 ? 0 : (which == 1 ? a.end0 : a.end1));
-        float m = a.m[which][j], v = a.v[which][j];
-        m = m + w1 * (g - m);
-        v = b2 * v + w2 * g * g;
-        a.m[which][j] = m;
-        a.v[which][j] = v;
-        a.w[which][j] -= step_size * m / (sqrtf(v) / c2s + a.eps);
+        adam_element(a, c, which, j, g);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {   // all workgroups have read the old step count
-            a.step[0][0] = t; a.step[1][0] = t; a.step[2][0] = t;
-            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float h = flat[2 * P] * ih, tl = flat[2 * P + 1] * it;
-            if (losses) { losses[0] = h + reg * tl; losses[1] = h; losses[2] = tl; }
-            if (loss_accum) { loss_accum[0] += h + reg * tl; loss_accum[1] += h; loss_accum[2] += tl; }
-            if (step_counter) step_counter[0] += 1;
-        }
-    }
+    adam_finish(a, c, mx, flat[2 * P] * ih, flat[2 * P + 1] * it, reg);
 }
 
 extern "C" int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
                                  float* loss_accum, int32_t* step_counter, void* stream) {
-    if (!flat || !adam) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL buffer");
+    if (!flat) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL buffer");
     AdamArgs a{};
-    int64_t P = 0;
-    for (int i = 0; i < 3; ++i) {
-        if (!adam->param[i] || !adam->exp_avg[i] || !adam->exp_avg_sq[i] || adam->numel[i] <= 0)
-            return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: parameter tensor %d: NULL pointer or non-positive size", i);
-        if (!adam->step[i]) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL step count of tensor %d", i);
-        a.w[i] = adam->param[i]; a.m[i] = adam->exp_avg[i]; a.v[i] = adam->exp_avg_sq[i]; a.step[i] = adam->step[i];
-        P += adam->numel[i];
-    }
-    if (!adam->ticket) return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: NULL ticket");
-    if (!(adam->lr > 0) || !(adam->beta1 >= 0 && adam->beta1 < 1) || !(adam->beta2 >= 0 && adam->beta2 < 1) || !(adam->eps >= 0))
-        return hjbx_set_error(HJBX_EINVAL, "hjbx_mix_adam_f32: bad hyper-parameters");
-    a.ticket = adam->ticket;
-    a.end0 = adam->numel[0]; a.end1 = adam->numel[0] + adam->numel[1]; a.P = P;
-    a.lr = adam->lr; a.b1 = adam->beta1; a.b2 = adam->beta2; a.eps = (float)adam->eps;
-    const int grid = (int)((P + 255) / 256 < 512 ? (P + 255) / 256 : 512);
-    hipLaunchKernelGGL(k_mix_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, flat, reg_dev, (float)reg, (float)eps, a, losses, loss_accum, step_counter);
+    if (int rc = adam_args_from(adam, "hjbx_mix_adam_f32", a)) return rc;
+    const MixArgs mx{reg_dev, (float)reg, (float)eps, losses, loss_accum, step_counter};
+    const int grid = (int)((a.P + 255) / 256 < 512 ? (a.P + 255) / 256 : 512);
+    hipLaunchKernelGGL(k_mix_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, flat, a, mx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_mix_adam_f32: %s", hipGetErrorString(e));
     return HJBX_OK;

@@ -22,7 +22,10 @@ int hjbx_set_error(int code, const char* fmt, ...);
 // current value of a hjbx_option (hjbx_set_option), 0 for an unknown one
 int hjbx_option_value(int option);
 
-// the cooperative single-kernel parameter gradient (hjbx_train_coop.hip), called by hjbx_value_loss_grad_f32 after argument validation
+// the cooperative single-kernel parameter gradient (hjbx_train_coop.hip), called by hjbx_value_loss_grad_f32 / hjbx_value_loss_adam_f32 after
+// argument validation.  fuse == NULL: the partial sums are reduced into `flat`; fuse != NULL (hjbx_adam.hpp): reduced, mixed and applied to the
+// weights by Adam in the same epilogue kernel, `flat` unused
+struct FuseArgs;
 int hjbx_train_coop(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost, const float* done,
-                    float* flat, void* workspace, int64_t B, void* stream);
+                    float* flat, void* workspace, int64_t B, void* stream, const FuseArgs* fuse);
 size_t hjbx_train_coop_workspace_bytes(int64_t B, int n);

@@ -32,6 +32,7 @@
 #include "hjbx_host.hpp"
 #include "hjbx_mlp_core.hpp"
 #include "hjbx_mlp_h2.hpp"
+#include "hjbx_adam.hpp"
 
 using namespace hjbx;
 
@@ -628,34 +629,34 @@ extern "C" size_t hjbx_value_loss_grad_workspace_bytes(int64_t B) {
     return coop > pair ? coop : pair;
 }
 
-extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
-                                        const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream) {
-    if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: NULL system, task or mlp descriptor");
+// argument checks shared by hjbx_value_loss_grad_f32 and hjbx_value_loss_adam_f32 (B > 0)
+static int check_vlg(const char* who, const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
+                     const float* done, const void* workspace, int64_t B) {
+    if (!sys || !task || !mlp) return hjbx_set_error(HJBX_EINVAL, "%s: NULL system, task or mlp descriptor", who);
     if (int rc = check_task(task)) return rc;
-    if (mode != HJBX_RESIDUAL_NORMALISED && mode != HJBX_RESIDUAL_RAW) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: unknown residual mode %d", mode);
-    if (B < 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: negative batch size");
-    if (!flat) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: flat output buffer is NULL");
-    const size_t P = (size_t)sys->n * kH1 + (size_t)kH1 * kH2 + (size_t)kH2 * kH3;
-    if (B == 0) {
-        hipError_t e = hipMemsetAsync(flat, 0, (2 * P + 4) * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-        return HJBX_OK;
-    }
+    if (mode != HJBX_RESIDUAL_NORMALISED && mode != HJBX_RESIDUAL_RAW) return hjbx_set_error(HJBX_EINVAL, "%s: unknown residual mode %d", who, mode);
+    if (B < 0) return hjbx_set_error(HJBX_EINVAL, "%s: negative batch size", who);
+    if (B == 0) return HJBX_OK;
     if (!x || !cost || !done || !workspace || !mlp->W1 || !mlp->W2 || !mlp->W3)
-        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x, cost, done, workspace and the weights must be non-NULL");
+        return hjbx_set_error(HJBX_EINVAL, "%s: x, cost, done, workspace and the weights must be non-NULL", who);
     if (mlp->h1 != kH1 || mlp->h2 != kH2 || mlp->h3 != kH3)
-        return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: features must be [128,128,64], got [%d,%d,%d]", mlp->h1, mlp->h2, mlp->h3);
+        return hjbx_set_error(HJBX_EUNSUPPORTED, "%s: features must be [128,128,64], got [%d,%d,%d]", who, mlp->h1, mlp->h2, mlp->h3);
     if (mlp->activation != HJBX_ACT_RELU && mlp->activation != HJBX_ACT_TANH && mlp->activation != HJBX_ACT_SIN)
-        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: unknown activation %d", mlp->activation);
+        return hjbx_set_error(HJBX_EINVAL, "%s: unknown activation %d", who, mlp->activation);
     const size_t row = (size_t)sys->n * sizeof(float);
     const uintptr_t am = (row % 16 == 0) ? 15u : 7u;
     if ((reinterpret_cast<uintptr_t>(x) & am) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
-        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: x must be aligned to its row vector width and workspace to 256 bytes");
+        return hjbx_set_error(HJBX_EINVAL, "%s: x must be aligned to its row vector width and workspace to 256 bytes", who);
     if ((reinterpret_cast<uintptr_t>(mlp->W1) | reinterpret_cast<uintptr_t>(mlp->W2) | reinterpret_cast<uintptr_t>(mlp->W3)) & 15u)
-        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: the weight matrices must be 16-byte aligned");
+        return hjbx_set_error(HJBX_EINVAL, "%s: the weight matrices must be 16-byte aligned", who);
     for (int k = 0; k < sys->n; ++k)
-        if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: normalization_std[%d] is zero", k);
-    if (!use_two_kernels(mlp->activation)) return hjbx_train_coop(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+        if (!(mlp->std[k] != 0.0)) return hjbx_set_error(HJBX_EINVAL, "%s: normalization_std[%d] is zero", who, k);
+    return HJBX_OK;
+}
+
+// the round-2 pair of kernels -> flat (arguments already validated)
+static int run_pair(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost, const float* done,
+                    float* flat, void* workspace, int64_t B, void* stream) {
     int rc = HJBX_EUNSUPPORTED;
 #ifdef HJBX_TRAIN_DEV   // development builds: cartpole only (the full set of instantiations takes minutes to compile)
     bool ok = false;
@@ -670,4 +671,49 @@ extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task*
     if (!ok || rc == HJBX_EUNSUPPORTED)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);
     return rc;
+}
+
+extern "C" int hjbx_value_loss_grad_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x,
+                                        const float* cost, const float* done, float* flat, void* workspace, int64_t B, void* stream) {
+    if (int rc = check_vlg("hjbx_value_loss_grad_f32", sys, task, mlp, mode, x, cost, done, workspace, B)) return rc;
+    if (!flat) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_grad_f32: flat output buffer is NULL");
+    const size_t P = (size_t)sys->n * kH1 + (size_t)kH1 * kH2 + (size_t)kH2 * kH3;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(flat, 0, (2 * P + 4) * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        return HJBX_OK;
+    }
+    if (!use_two_kernels(mlp->activation)) return hjbx_train_coop(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream, nullptr);
+    return run_pair(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+}
+
+// ---- params_update in one call (vhjb.py:255-288): gradient + counts + mix + losses + Adam -------------------------------------------------
+// Cooperative path: two launches (k_train_coop, then the reduction of its partial sums, the mix and the Adam step in ONE epilogue kernel; the
+// flat buffer is never written).  Pair path (f16x2 chains / HJBX_OPT_TRAIN_KERNEL = 1): the flat buffer goes to the tail of the workspace and
+// hjbx_mix_adam_f32's kernel follows.  Single process only: a data-parallel step needs the flat buffer for its all-reduce.
+extern "C" size_t hjbx_value_loss_adam_workspace_bytes(int64_t B) {
+    if (B <= 0) return 0;
+    const size_t P = (size_t)HJBX_MAX_N * kH1 + (size_t)kH1 * kH2 + (size_t)kH2 * kH3;
+    return ((hjbx_value_loss_grad_workspace_bytes(B) + 255) & ~(size_t)255) + (((2 * P + 4) * sizeof(float) + 255) & ~(size_t)255);
+}
+
+extern "C" int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
+                                 float* loss_accum, int32_t* step_counter, void* stream);
+
+extern "C" int hjbx_value_loss_adam_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
+                                        const float* done, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
+                                        float* loss_accum, int32_t* step_counter, void* workspace, int64_t B, void* stream) {
+    if (int rc = check_vlg("hjbx_value_loss_adam_f32", sys, task, mlp, mode, x, cost, done, workspace, B)) return rc;
+    if (B == 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: empty minibatch");
+    FuseArgs f{};
+    if (int rc = adam_args_from(adam, "hjbx_value_loss_adam_f32", f.a)) return rc;
+    if (adam->param[0] != mlp->W1 || adam->param[1] != mlp->W2 || adam->param[2] != mlp->W3)
+        return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the Adam state's parameters must be the network's W1, W2, W3");
+    const int64_t P = (int64_t)sys->n * kH1 + (int64_t)kH1 * kH2 + (int64_t)kH2 * kH3;
+    if (f.a.P != P) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the Adam state holds %lld parameters, the network %lld", (long long)f.a.P, (long long)P);
+    f.mx = MixArgs{reg_dev, (float)reg, (float)eps, losses, loss_accum, step_counter};
+    if (!use_two_kernels(mlp->activation)) return hjbx_train_coop(sys, task, mlp, mode, x, cost, done, nullptr, workspace, B, stream, &f);
+    float* flat = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((hjbx_value_loss_grad_workspace_bytes(B) + 255) & ~(size_t)255));
+    if (int rc = run_pair(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream)) return rc;
+    return hjbx_mix_adam_f32(flat, reg_dev, reg, eps, adam, losses, loss_accum, step_counter, stream);
 }

@@ -35,6 +35,7 @@
 #include "hjbx_systems.hpp"
 #include "hjbx_host.hpp"
 #include "hjbx_mlp_core.hpp"
+#include "hjbx_adam.hpp"
 
 using namespace hjbx;
 
@@ -42,6 +43,7 @@ static constexpr int kExLd = 33;                      // row stride of an exchan
 static constexpr int kExFloats = 128 * kExLd;
 static constexpr int kCoopBlocks = 48;                // per set 24: dW2 (ib, jb) -> ib * 4 + jb; dW3 (ib, jb) -> 16 + ib * 2 + jb
 static constexpr int kCoopSet = 24;
+static constexpr int kCoopMaxGrid = 512;             // workgroups of a launch (one per CU at most) the fused epilogue keeps records for
 
 template <int N> struct CoopLds {
     static constexpr int NP = (N + 3) & ~3;
@@ -617,6 +619,33 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     }
 }
 
+// Sum of `count` records base[g stride] in a FIXED order: eight interleaved running sums (eight loads in flight: these reductions are latency
+// bound at the reference's minibatch), then ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)).  Two of them at once for the fused epilogue.
+__device__ __forceinline__ float coop_sum8(const float* __restrict__ base, int64_t stride, int count) {
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int gI = 0;
+    for (; gI + 8 <= count; gI += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] += base[(int64_t)(gI + k) * stride];
+    }
+    for (int k = 0; gI < count; ++gI, ++k) s8[k] += base[(int64_t)gI * stride];
+    return ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+}
+__device__ __forceinline__ void coop_sum8x2(const float* __restrict__ a, const float* __restrict__ b, int64_t stride, int count, float& sa, float& sb) {
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int gI = 0;
+    for (; gI + 8 <= count; gI += 8) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { va[k] = a[(int64_t)(gI + k) * stride]; vb[k] = b[(int64_t)(gI + k) * stride]; }   // sixteen loads in flight
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { p[k] += va[k]; q[k] += vb[k]; }
+    }
+    for (int k = 0; gI < count; ++gI, ++k) { p[k] += a[(int64_t)gI * stride]; q[k] += b[(int64_t)gI * stride]; }
+    sa = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    sb = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+}
+
 // ---- partial sums -> flat gradient buffer, in workgroup order ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts,
@@ -624,15 +653,7 @@ __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restri
     constexpr int P = N * kH1 + kH1 * kH2 + kH2 * kH3;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < kCoopBlocks * 1024) {
-        // fixed order: four interleaved running sums over the workgroups (four loads in flight), then ((s0 + s1) + (s2 + s3))
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
-        int gI = 0;
-        for (; gI + 4 <= nparts; gI += 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s4[k] += partial[(int64_t)(gI + k) * kCoopBlocks * 1024 + t];
-        }
-        for (int k = 0; gI < nparts; ++gI, ++k) s4[k] += partial[(int64_t)gI * kCoopBlocks * 1024 + t];
-        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        const float s = coop_sum8(partial + t, (int64_t)kCoopBlocks * 1024, nparts);
         const int blk = t >> 10, reg = (t >> 6) & 15, lane = t & 63;
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
         const int set = blk / kCoopSet, b = blk % kCoopSet;
@@ -641,22 +662,60 @@ __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restri
         else o[N * kH1 + kH1 * kH2 + (32 * ((b - 16) >> 1) + row) * kH3 + 32 * ((b - 16) & 1) + col] = s;
     } else if (t < kCoopBlocks * 1024 + 2 * N * 128) {
         const int u = t - kCoopBlocks * 1024;          // (set, k, f)
-        float s4[4] = {0.f, 0.f, 0.f, 0.f};
-        const int np2 = 2 * nparts;                    // two sample halves per workgroup
-        int gI = 0;
-        for (; gI + 4 <= np2; gI += 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s4[k] += partial_w1[(int64_t)(gI + k) * (2 * N * 128) + u];
-        }
-        for (int k = 0; gI < np2; ++gI, ++k) s4[k] += partial_w1[(int64_t)gI * (2 * N * 128) + u];
         const int set = u / (N * 128), kf = u % (N * 128);
-        flat[set * P + kf] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        flat[set * P + kf] = coop_sum8(partial_w1 + u, 2 * N * 128, 2 * nparts);                      // two sample halves per workgroup
     } else if (t < kCoopBlocks * 1024 + 2 * N * 128 + 4) {
         const int k = t - (kCoopBlocks * 1024 + 2 * N * 128);
         double s = 0;
         for (int g = 0; g < nparts; ++g) s += sums_rec[4 * g + k];
         flat[2 * P + k] = (float)s;
     }
+}
+
+// ---- partial sums -> mixed gradient -> Adam, in workgroup order, one launch (hjbx_value_loss_adam_f32) ------------------------------------
+// The same sums in the same order as k_train_coop_reduce, but each thread takes ONE parameter of BOTH sets (hjb, termination), divides by the
+// counts, mixes (vhjb.py:241, 253, 284) and applies optax.adam's update (hjbx_adam.hpp) to it: the flat buffer is never written.  At the
+// reference's minibatch this removes one launch-bound kernel from the update (gather -> gradient -> this).
+template <int N>
+__global__ __launch_bounds__(256) void k_train_coop_update(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts,
+                                                          const double* __restrict__ sums_rec, AdamArgs a, MixArgs mx) {
+    __shared__ float sc[2];
+    __shared__ double tot[4];
+    __shared__ double rec[4 * kCoopMaxGrid];          // the loss-sum records of the workgroups (at most one workgroup per CU)
+    // Order of work: everything that needs no other thread first -- thread 0's bias corrections (double pow), the records into LDS, and each
+    // thread's own long sums over the workgroups -- then ONE barrier, the four scalar totals, a second barrier, mix + Adam.  (Written in
+    // program order -- coefficients, totals, sums -- every thread waited through two serial latencies before it started its loads: 54 us per
+    // 256-sample update instead of 47.)
+    const float tstep = adam_coef_begin(a, sc);
+    for (int idx = threadIdx.x; idx < 4 * nparts; idx += 256) rec[idx] = sums_rec[idx];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float sh = 0.f, st = 0.f;
+    int which = -1;
+    int64_t j = 0;
+    if (t < kCoopSet * 1024) {
+        coop_sum8x2(partial + t, partial + kCoopSet * 1024 + t, (int64_t)kCoopBlocks * 1024, nparts, sh, st);
+        const int b = t >> 10, reg16 = (t >> 6) & 15, lane = t & 63;
+        const int row = (reg16 & 3) + 8 * (reg16 >> 2) + 4 * (lane >> 5), col = lane & 31;
+        if (b < 16) { which = 1; j = (int64_t)(32 * (b >> 2) + row) * kH2 + 32 * (b & 3) + col; }
+        else { which = 2; j = (int64_t)(32 * ((b - 16) >> 1) + row) * kH3 + 32 * ((b - 16) & 1) + col; }
+    } else if (t < kCoopSet * 1024 + N * 128) {
+        const int kf = t - kCoopSet * 1024;            // (k, f) of W1
+        coop_sum8x2(partial_w1 + kf, partial_w1 + N * 128 + kf, 2 * N * 128, 2 * nparts, sh, st);   // two sample halves per workgroup
+        which = 0; j = kf;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {   // loss sums and counts: the records in workgroup order, like k_train_coop_reduce (every workgroup computes them)
+        double s = 0;
+        for (int g = 0; g < nparts; ++g) s += rec[4 * g + threadIdx.x];
+        tot[threadIdx.x] = (double)(float)s;          // (the flat buffer holds them as float32)
+    }
+    __syncthreads();
+    const AdamCoef c = adam_coef_end(a, tstep, sc);
+    const float reg = mx.reg_dev ? mx.reg_dev[0] : mx.reg_host;
+    const float ih = 1.0f / ((float)tot[2] + mx.eps), it = 1.0f / ((float)tot[3] + mx.eps);
+    const float wt = reg * it;
+    if (which >= 0) adam_element(a, c, which, j, sh * ih + st * wt);
+    adam_finish(a, c, mx, (float)tot[0] * ih, (float)tot[1] * it, reg);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
@@ -680,7 +739,7 @@ size_t hjbx_train_coop_workspace_bytes(int64_t B, int n) { return B > 0 ? coop_w
 
 template <typename S>
 static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
-                       const float* done, float* flat, void* workspace, int64_t B, void* st) {
+                       const float* done, float* flat, void* workspace, int64_t B, void* st, const FuseArgs* fuse) {
     constexpr int N = S::N, M = S::M;
     if constexpr (N % 2 != 0 || N > HJBX_MAX_N) {
         return HJBX_EUNSUPPORTED;
@@ -718,8 +777,16 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
         };
         if (mode == HJBX_RESIDUAL_NORMALISED) with_act(std::integral_constant<int, 0>{});
         else with_act(std::integral_constant<int, 1>{});
-        const int nthreads = kCoopBlocks * 1024 + 2 * N * 128 + 4;
-        hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, flat);
+        if (fuse) {
+            if (fuse->a.end0 != N * kH1 || fuse->a.end1 - fuse->a.end0 != kH1 * kH2 || fuse->a.P - fuse->a.end1 != kH2 * kH3)
+                return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the Adam state's tensors must be W1 (%d x 128), W2 (128 x 128), W3 (128 x 64)", N);
+            if (w.grid > kCoopMaxGrid) return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_adam_f32: %d workgroups (more than %d CUs?)", w.grid, kCoopMaxGrid);
+            const int nthreads = kCoopSet * 1024 + N * 128;
+            hipLaunchKernelGGL((k_train_coop_update<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, fuse->a, fuse->mx);
+        } else {
+            const int nthreads = kCoopBlocks * 1024 + 2 * N * 128 + 4;
+            hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, flat);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: %s", hipGetErrorString(e));
         return HJBX_OK;
@@ -728,7 +795,7 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
 
 // called by hjbx_value_loss_grad_f32 (hjbx_train.hip) after it has validated its arguments
 int hjbx_train_coop(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost, const float* done,
-                    float* flat, void* workspace, int64_t B, void* stream) {
+                    float* flat, void* workspace, int64_t B, void* stream, const FuseArgs* fuse) {
     if (mlp->activation == HJBX_ACT_SIN && sys->n > 4)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: the sin network's fused parameter gradient exists for n <= 4 (n = %d)", sys->n);
     int rc = HJBX_EUNSUPPORTED;
@@ -736,15 +803,15 @@ int hjbx_train_coop(const hjbx_system* sys, const hjbx_task* task, const hjbx_ml
     bool ok = false;
     if (sys->kind == HJBX_SYS_CARTPOLE) {
         Cartpole<float> cp{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
-        rc = launch_coop<Cartpole<float>>(sys, cp, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+        rc = launch_coop<Cartpole<float>>(sys, cp, task, mlp, mode, x, cost, done, flat, workspace, B, stream, fuse);
         ok = true;
     } else if (sys->kind == HJBX_SYS_NEARHOVER) {
         NearHover<float> q{(float)sys->p[0], (float)sys->p[1], (float)sys->p[2], (float)sys->p[3]};
-        rc = launch_coop<NearHover<float>>(sys, q, task, mlp, mode, x, cost, done, flat, workspace, B, stream);
+        rc = launch_coop<NearHover<float>>(sys, q, task, mlp, mode, x, cost, done, flat, workspace, B, stream, fuse);
         ok = true;
     }
 #else
-    const bool ok = with_system<float>(sys, [&](auto S) { rc = launch_coop<decltype(S)>(sys, S, task, mlp, mode, x, cost, done, flat, workspace, B, stream); });
+    const bool ok = with_system<float>(sys, [&](auto S) { rc = launch_coop<decltype(S)>(sys, S, task, mlp, mode, x, cost, done, flat, workspace, B, stream, fuse); });
 #endif
     if (!ok || rc == HJBX_EUNSUPPORTED)
         return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_grad_f32: no kernel for system kind %d with n=%d m=%d", sys->kind, sys->n, sys->m);

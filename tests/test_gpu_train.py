@@ -341,3 +341,44 @@ def test_mix_adam_follows_torch_adam_step_for_step():
             assert torch.allclose(mm, st["exp_avg"], rtol=1e-5, atol=1e-9) and torch.allclose(vv, st["exp_avg_sq"], rtol=1e-5, atol=1e-12)
             assert (w - p).abs().max().item() <= 2e-6 * lr * (it + 1) + 1e-7 * p.abs().max().item()
     assert int(counter) == 10 and torch.allclose(acc, want_acc, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,activation", [("cartpole", "relu"), ("quad2d", "tanh"), ("nearhover", "relu"), ("linear", "sin")])
+def test_value_loss_adam_equals_gradient_then_mix_adam(name, activation, impl):
+    """hjbx_value_loss_adam_f32 (params_update in one call: on the cooperative path the reduction of the partial sums, the mix and the Adam
+    step share one epilogue kernel and the flat buffer is never written) == hjbx_value_loss_grad_f32 followed by hjbx_mix_adam_f32: the same
+    sums in the same order, so weights, moments, step counts, losses and the device-side counters agree bit for bit; three steps."""
+    if activation != "relu" and impl != "coop/f32":
+        pytest.skip("tanh / sin exist in the cooperative kernel only")
+    d, ctl = controller(name, activation=activation)
+    vf = ctl.value_function_approximator
+    xs, dones, costs = _batch(d, ctl, 300, 13)
+    state = []
+    for fused in (True, False):
+        g = torch.Generator(device="cuda").manual_seed(2)
+        w = [p.detach().clone().contiguous() for p in vf.parameters()]
+        m = [torch.rand(p.shape, generator=g, device="cuda") * 1e-3 for p in w]
+        v = [torch.rand(p.shape, generator=g, device="cuda") * 1e-5 for p in w]
+        steps = [torch.full((), 4.0, device="cuda") for _ in w]
+        ticket, acc, counter = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(3, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        desc = vf.descriptor()
+        desc.W1, desc.W2, desc.W3 = (t.data_ptr() for t in w)
+        out = []
+        for it in range(3):
+            reg = 0.2 * (it + 1)
+            if fused:
+                losses = _ops.value_loss_adam(d.system, ctl._task, desc, xs, costs, dones, ctl.residual_mode, reg, ctl.epsilon, w, m, v, steps, ticket, 1e-3, 0.9,
+                                              0.999, 1e-8, acc, counter)
+            else:
+                flat = _ops.value_loss_grad(d.system, ctl._task, desc, xs, costs, dones, mode=ctl.residual_mode)
+                losses = _ops.mix_adam(flat, reg, ctl.epsilon, w, m, v, steps, ticket, 1e-3, 0.9, 0.999, 1e-8, acc, counter)
+            out.append(losses.clone())
+        torch.cuda.synchronize()
+        state.append((w, m, v, steps, acc, counter, out, ticket))
+    a, b = state
+    assert int(a[5]) == int(b[5]) == 3 and int(a[7]) == int(b[7]) == 0 and all(float(x) == float(y) == 7.0 for x, y in zip(a[3], b[3]))
+    for k in (0, 1, 2):
+        for ta, tb in zip(a[k], b[k]):
+            assert torch.equal(ta, tb), (k, float((ta - tb).abs().max()))
+    assert torch.equal(a[4], b[4]) and all(torch.equal(x, y) for x, y in zip(a[6], b[6]))
+    assert all(float((p - q).abs().max()) > 0 for p, q in zip(a[0], vf.parameters()))              # the weights did move
