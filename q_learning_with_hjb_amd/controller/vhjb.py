@@ -828,7 +828,7 @@ def capture_step(optimizer, params, step_fn, dev, before_each=None):
 
 class FitGraph:
     """The optimiser step of the fit phase with its minibatch selection inside the graph (VHJBController._fit_epoch_graphed):
-    hjbx_replay_gather_f32 -> hjbx_value_loss_grad_f32 -> hjbx_mix_adam_f32.  Static buffers: perm (replay capacity, int32), reg_table (one
+    hjbx_replay_gather_f32 -> hjbx_value_loss_adam_f32 (gradient kernel + one reduce / mix / Adam epilogue).  Static buffers: perm (replay capacity, int32), reg_table (one
     entry per update of an epoch), step (device update counter within the epoch), loss_accum (3 running loss sums).  Because nothing on the
     host changes between two updates, UNROLL consecutive updates are also captured as one graph: a launch of that graph pays the
     graph-to-graph gap (about 8 us on MI355X) once per UNROLL updates."""
