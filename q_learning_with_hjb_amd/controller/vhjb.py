@@ -571,7 +571,8 @@ class VHJBController(Controller):
         if self.fused_param_grad:
             # one C-ABI call: [d sum(hjb)/dW | d sum(termination)/dW | sum hjb, sum termination, #interior, #done] -- exactly the buffer
             # the data-parallel step all-reduces once; then the division by the (global) counts and the mix (vhjb.py:241, 253, 284)
-            if self._native_adam and not self._distributed():
+            if (self._native_adam and not self._distributed() and type(self).value_loss_gradient is VHJBController.value_loss_gradient
+                    and "value_loss_gradient" not in self.__dict__):
                 # one process: gradient, counts, mix, the three losses and optax.adam's step (vhjb.py:120, 262-263) in ONE C-ABI call of two
                 # launches -- the flat buffer is not even materialised (hjbx_value_loss_adam_f32), on the optimiser's own state tensors
                 m, v, step = self._adam_state(model_params)
