@@ -216,17 +216,17 @@ HJBX_DEV double wave_sum(double v) {
 
 template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, unsigned char* ws, T* __restrict__ sums) {
     __shared__ double lds[3][kBlock / 64];
+    __shared__ unsigned last_s;
     a = wave_sum(a);
     b = wave_sum(b);
     c = wave_sum(c);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { lds[0][wave] = a; lds[1][wave] = b; lds[2][wave] = c; }
     __syncthreads();
-    if (wave != 0) return;
     unsigned* cnt = reinterpret_cast<unsigned*>(ws);
     double* rec = reinterpret_cast<double*>(ws + kCounterBytes);
-    unsigned last = 0;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
+        unsigned last = 0;
         double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) { s0 += lds[0][w]; s1 += lds[1][w]; s2 += lds[2][w]; }
@@ -251,17 +251,42 @@ template <typename T> HJBX_DEV void block_sum3(double a, double b, double c, uns
                 last = 1;
             }
         }
+        last_s = last;
     }
-    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+    __syncthreads();
+    if (!last_s) return;
+    // The last workgroup to arrive adds the records -- with ALL its threads and every load issued before the first add (one memory latency
+    // instead of gridDim / 64 of them one after the other on one wave: that serial loop was ~4 us of the 18 us the cartpole entry point takes at
+    // B = 2^20), in a fixed order: thread t takes records t, t + 256, ..., then the fixed shuffle tree, then the waves in index order.
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    constexpr int PER = (kReduceBlocks + kBlock - 1) / kBlock;
+    double va[PER], vb[PER], vc[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const unsigned r = threadIdx.x + q * kBlock;
+        const bool in = r < gridDim.x;
+        va[q] = in ? __hip_atomic_load(rec + 3 * (size_t)r + 0, HJBX_RLX_AGENT) : 0.0;
+        vb[q] = in ? __hip_atomic_load(rec + 3 * (size_t)r + 1, HJBX_RLX_AGENT) : 0.0;
+        vc[q] = in ? __hip_atomic_load(rec + 3 * (size_t)r + 2, HJBX_RLX_AGENT) : 0.0;
+    }
     double fa = 0, fb = 0, fc = 0;
-    for (unsigned r = lane; r < gridDim.x; r += 64) {      // records in index order per lane, then the fixed shuffle tree
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { fa += va[q]; fb += vb[q]; fc += vc[q]; }
+    for (unsigned r = threadIdx.x + PER * kBlock; r < gridDim.x; r += kBlock) {      // (grids beyond kReduceBlocks: not launched by this library)
         fa += __hip_atomic_load(rec + 3 * (size_t)r + 0, HJBX_RLX_AGENT);
         fb += __hip_atomic_load(rec + 3 * (size_t)r + 1, HJBX_RLX_AGENT);
         fc += __hip_atomic_load(rec + 3 * (size_t)r + 2, HJBX_RLX_AGENT);
     }
     fa = wave_sum(fa); fb = wave_sum(fb); fc = wave_sum(fc);
-    if (lane == 0) { sums[0] = (T)fa; sums[1] = (T)fb; sums[2] = (T)fc; }
+    __syncthreads();                                  // (lds is reused: every thread has passed the first use)
+    if (lane == 0) { lds[0][wave] = fa; lds[1][wave] = fb; lds[2][wave] = fc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { s0 += lds[0][w]; s1 += lds[1][w]; s2 += lds[2][w]; }
+        sums[0] = (T)s0; sums[1] = (T)s1; sums[2] = (T)s2;
+    }
 }
 
 // hjb_loss body (vhjb.py:227-241) + analytic d loss_i / d gradV
