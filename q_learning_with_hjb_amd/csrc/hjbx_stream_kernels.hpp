@@ -46,7 +46,11 @@ template <typename T, int N> struct RowIO {
 
 static constexpr int kBlock = 256;        // 4 waves per workgroup
 static constexpr uint32_t kRolloutTerminate = 1u, kRolloutStopAtTarget = 2u;   // HJBX_ROLLOUT_* of include/hjbx.h (this header must compile without it)
-static constexpr int kReduceBlocks = 1024;  // grid cap of the reducing kernels (4 per CU); 4096 measured no better
+#ifndef HJBX_REDUCE_BLOCKS
+#define HJBX_REDUCE_BLOCKS 1024
+#endif
+static constexpr int kReduceBlocks = HJBX_REDUCE_BLOCKS;  // grid cap of the reducing kernels (4 per CU).  Measured again in round 3 with the parallel final
+                                                          // reduction (hjb_residual, B = 2^20, cartpole / near-hover): 1024: 16.8 / 33.4 us, 2048: 17.5 / 35.2, 4096: 23.5 / 38.3
 
 // ----------------------------------------------------------------------------------------------
 // pointwise kernels
