@@ -834,7 +834,7 @@ class FitGraph:
     host changes between two updates, UNROLL consecutive updates are also captured as one graph: a launch of that graph pays the
     graph-to-graph gap (about 8 us on MI355X) once per UNROLL updates."""
 
-    UNROLL = 8
+    UNROLL = int(os.environ.get("HJBX_FIT_UNROLL", "8"))     # measured (cartpole, 256 samples): 4: 0.0444, 8: 0.0438, 16 / 32: 0.0430 ms per update
 
     def __init__(self, ctl, batch: int):
         rb, dev = ctl.replay_buffer, ctl.device
