@@ -584,16 +584,12 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[blk * 1024 + r * 64 + lane] = a[r];
     };
-    if constexpr (PS == 4) {   // this part's column block; the other blocks of this workgroup's record are zero
-        f32x16 zero;
-        zero16(zero);
-        for (int j = 0; j < 4; ++j) {
-            put(w * 4 + j, j == part ? acc2h[0] : zero);
-            put(kCoopSet + w * 4 + j, j == part ? acc2t[0] : zero);
-        }
-        for (int j = 0; j < 2; ++j) {
-            put(16 + w * 2 + j, (do3 && j == (part & 1)) ? acc3h[0] : zero);
-            put(kCoopSet + 16 + w * 2 + j, (do3 && j == (part & 1)) ? acc3t[0] : zero);
+    if constexpr (PS == 4) {   // only the blocks this part owns are written -- and only those are read: the epilogue kernels know the ownership
+        put(w * 4 + part, acc2h[0]);
+        put(kCoopSet + w * 4 + part, acc2t[0]);
+        if (do3) {
+            put(16 + w * 2 + (part & 1), acc3h[0]);
+            put(kCoopSet + 16 + w * 2 + (part & 1), acc3t[0]);
         }
     } else {
 #pragma unroll
@@ -601,10 +597,12 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
 #pragma unroll
         for (int j = 0; j < NB3; ++j) { put(16 + w * 2 + j, acc3h[j]); put(kCoopSet + 16 + w * 2 + j, acc3t[j]); }
     }
-    float* o1 = partial_w1 + ((int64_t)blockIdx.x * 2 + (tid >> 7)) * (2 * N * 128);
+    if (own1) {     // (PS = 4: dW1 and the loss sums belong to part 0)
+        float* o1 = partial_w1 + ((int64_t)blockIdx.x * 2 + (tid >> 7)) * (2 * N * 128);
 #pragma unroll
-    for (int k = 0; k < N; ++k) { o1[k * 128 + fW1] = w1h[k >> 1][k & 1]; o1[(N + k) * 128 + fW1] = w1t[k >> 1][k & 1]; }
-    if (w == 0) {   // loss sums and counts: sample slots -> wave (fixed shuffle tree) -> one record
+        for (int k = 0; k < N; ++k) { o1[k * 128 + fW1] = w1h[k >> 1][k & 1]; o1[(N + k) * 128 + fW1] = w1t[k >> 1][k & 1]; }
+    }
+    if (w == 0 && own1) {   // loss sums and counts: sample slots -> wave (fixed shuffle tree) -> one record
         double acc_h = h == 0 ? L.sums[0][i] : 0.0, acc_t = h == 0 ? L.sums[1][i] : 0.0;
         double acc_ni = h == 0 ? L.sums[2][i] : 0.0, acc_nd = h == 0 ? L.sums[3][i] : 0.0;
 #pragma unroll
@@ -646,14 +644,34 @@ __device__ __forceinline__ void coop_sum8x2(const float* __restrict__ a, const f
     sb = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
 }
 
+// dW1: two records (sample halves) per owning workgroup.  psplit = 1: the 2 nparts records in order (one sequence); psplit = 4: the owners are the
+// workgroups 0, 4, 8, ..., i.e. the records 8 ts + half -- the two halves as two sequences, added at the end
+template <int N> __device__ __forceinline__ float coop_sum_w1(const float* __restrict__ base /* partial_w1 + (set, k, f) */, int nparts, int psplit) {
+    if (psplit != 4) return coop_sum8(base, 2 * N * 128, 2 * nparts);
+    float s0, s1;
+    coop_sum8x2(base, base + 2 * N * 128, (int64_t)8 * (2 * N * 128), nparts / 4, s0, s1);
+    return s0 + s1;
+}
+
+// Which workgroups hold a block of the partial sums.  psplit = 1: every workgroup, all of it.  psplit = 4 (k_train_coop<.., PS = 4, ..>: four
+// workgroups per tile): output block b of dW2 / dW3 lives only in the workgroups whose part is b's column block, dW1 and the loss sums only in
+// part 0 -- a quarter of the records to add at the reference's minibatch.  -> first workgroup, step between workgroups, number of them
+struct CoopOwners { int first, step, count; };
+__device__ __forceinline__ CoopOwners coop_owners(int b /* block within its set, or -1: dW1 / loss sums */, int nparts, int psplit) {
+    if (psplit != 4) return CoopOwners{0, 1, nparts};
+    const int jb = b < 0 ? 0 : (b < 16 ? (b & 3) : ((b - 16) & 1));
+    return CoopOwners{jb, 4, nparts / 4};
+}
+
 // ---- partial sums -> flat gradient buffer, in workgroup order ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts,
+__global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts, int psplit,
                                                           const double* __restrict__ sums_rec, float* __restrict__ flat) {
     constexpr int P = N * kH1 + kH1 * kH2 + kH2 * kH3;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < kCoopBlocks * 1024) {
-        const float s = coop_sum8(partial + t, (int64_t)kCoopBlocks * 1024, nparts);
+        const CoopOwners ow = coop_owners((t >> 10) % kCoopSet, nparts, psplit);
+        const float s = coop_sum8(partial + (int64_t)ow.first * kCoopBlocks * 1024 + t, (int64_t)ow.step * kCoopBlocks * 1024, ow.count);
         const int blk = t >> 10, reg = (t >> 6) & 15, lane = t & 63;
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
         const int set = blk / kCoopSet, b = blk % kCoopSet;
@@ -663,11 +681,12 @@ __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restri
     } else if (t < kCoopBlocks * 1024 + 2 * N * 128) {
         const int u = t - kCoopBlocks * 1024;          // (set, k, f)
         const int set = u / (N * 128), kf = u % (N * 128);
-        flat[set * P + kf] = coop_sum8(partial_w1 + u, 2 * N * 128, 2 * nparts);                      // two sample halves per workgroup
+        flat[set * P + kf] = coop_sum_w1<N>(partial_w1 + u, nparts, psplit);
     } else if (t < kCoopBlocks * 1024 + 2 * N * 128 + 4) {
         const int k = t - (kCoopBlocks * 1024 + 2 * N * 128);
+        const CoopOwners ow = coop_owners(-1, nparts, psplit);
         double s = 0;
-        for (int g = 0; g < nparts; ++g) s += sums_rec[4 * g + k];
+        for (int g = 0; g < ow.count; ++g) s += sums_rec[4 * (ow.first + g * ow.step) + k];
         flat[2 * P + k] = (float)s;
     }
 }
@@ -677,7 +696,7 @@ __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restri
 // counts, mixes (vhjb.py:241, 253, 284) and applies optax.adam's update (hjbx_adam.hpp) to it: the flat buffer is never written.  At the
 // reference's minibatch this removes one launch-bound kernel from the update (gather -> gradient -> this).
 template <int N>
-__global__ __launch_bounds__(256) void k_train_coop_update(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts,
+__global__ __launch_bounds__(256) void k_train_coop_update(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts, int psplit,
                                                           const double* __restrict__ sums_rec, AdamArgs a, MixArgs mx) {
     __shared__ float sc[2];
     __shared__ double tot[4];
@@ -693,20 +712,24 @@ __global__ __launch_bounds__(256) void k_train_coop_update(const float* __restri
     int which = -1;
     int64_t j = 0;
     if (t < kCoopSet * 1024) {
-        coop_sum8x2(partial + t, partial + kCoopSet * 1024 + t, (int64_t)kCoopBlocks * 1024, nparts, sh, st);
         const int b = t >> 10, reg16 = (t >> 6) & 15, lane = t & 63;
+        const CoopOwners ow = coop_owners(b, nparts, psplit);
+        const float* src = partial + (int64_t)ow.first * kCoopBlocks * 1024 + t;
+        coop_sum8x2(src, src + kCoopSet * 1024, (int64_t)ow.step * kCoopBlocks * 1024, ow.count, sh, st);
         const int row = (reg16 & 3) + 8 * (reg16 >> 2) + 4 * (lane >> 5), col = lane & 31;
         if (b < 16) { which = 1; j = (int64_t)(32 * (b >> 2) + row) * kH2 + 32 * (b & 3) + col; }
         else { which = 2; j = (int64_t)(32 * ((b - 16) >> 1) + row) * kH3 + 32 * ((b - 16) & 1) + col; }
     } else if (t < kCoopSet * 1024 + N * 128) {
         const int kf = t - kCoopSet * 1024;            // (k, f) of W1
-        coop_sum8x2(partial_w1 + kf, partial_w1 + N * 128 + kf, 2 * N * 128, 2 * nparts, sh, st);   // two sample halves per workgroup
+        sh = coop_sum_w1<N>(partial_w1 + kf, nparts, psplit);
+        st = coop_sum_w1<N>(partial_w1 + N * 128 + kf, nparts, psplit);
         which = 0; j = kf;
     }
     __syncthreads();
     if (threadIdx.x < 4) {   // loss sums and counts: the records in workgroup order, like k_train_coop_reduce (every workgroup computes them)
+        const CoopOwners ow = coop_owners(-1, nparts, psplit);
         double s = 0;
-        for (int g = 0; g < nparts; ++g) s += rec[4 * g + threadIdx.x];
+        for (int g = 0; g < ow.count; ++g) s += rec[4 * (ow.first + g * ow.step) + threadIdx.x];
         tot[threadIdx.x] = (double)(float)s;          // (the flat buffer holds them as float32)
     }
     __syncthreads();
@@ -782,10 +805,10 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
                 return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the Adam state's tensors must be W1 (%d x 128), W2 (128 x 128), W3 (128 x 64)", N);
             if (w.grid > kCoopMaxGrid) return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_adam_f32: %d workgroups (more than %d CUs?)", w.grid, kCoopMaxGrid);
             const int nthreads = kCoopSet * 1024 + N * 128;
-            hipLaunchKernelGGL((k_train_coop_update<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, fuse->a, fuse->mx);
+            hipLaunchKernelGGL((k_train_coop_update<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, w.psplit, sums, fuse->a, fuse->mx);
         } else {
             const int nthreads = kCoopBlocks * 1024 + 2 * N * 128 + 4;
-            hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, sums, flat);
+            hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, w.psplit, sums, flat);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_value_loss_grad_f32: %s", hipGetErrorString(e));
