@@ -175,8 +175,14 @@ __device__ __forceinline__ void coop_outer(f32x16 (&acch)[NB], LPc Ah, LPc Bh, f
 #endif
 #ifdef HJBX_COOP_NO_BARRIER
 #define COOP_SYNC() __builtin_amdgcn_sched_barrier(0)
+#elif defined(HJBX_COOP_STAMPS)   // development: wall-clock stamps (100 MHz) of one non-owner workgroup at every barrier, into its unused dW1 record
+#define COOP_STAMP() do { if (stamp_on) stamp_buf[stamp_idx++] = wall_clock64(); } while (0)
+#define COOP_SYNC() do { __syncthreads(); COOP_STAMP(); } while (0)
 #else
 #define COOP_SYNC() __syncthreads()
+#endif
+#ifndef COOP_STAMP
+#define COOP_STAMP() do { } while (0)
 #endif
 
 template <int MODE, int ACT, int PS, typename S>
@@ -195,22 +201,49 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
     __shared__ TaskP<float, N, M> tk_s;
     __shared__ Limits<float, M> lim_s;
     const int tid = threadIdx.x;
+#ifdef HJBX_COOP_STAMPS
+    const bool stamp_on = PS == 4 && blockIdx.x == 1 && tid == 0;
+    unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(partial_w1 + (int64_t)blockIdx.x * 2 * (2 * S::N * 128));
+    int stamp_idx = 0;
+    COOP_STAMP();                                                                       // 0: kernel entry
+#endif
     if (tid == 0) { sys_s = sys_k; p_s = p_k; tk_s = tk_k; lim_s = lim_k; }
+#ifndef HJBX_COOP_NO_FILL   // (development timing switch, see COOP_OUTER)
     {   // weights -> LDS (odd row strides), 16 bytes per global load: at the reference's minibatch (8 tiles) this fill is on the latency path
         static_assert(kH1 % 4 == 0 && kH2 % 4 == 0 && kH3 % 4 == 0, "");
         const float4* W1v = reinterpret_cast<const float4*>(W1g);
         const float4* W2v = reinterpret_cast<const float4*>(W2g);
         const float4* W3v = reinterpret_cast<const float4*>(W3g);
         auto put4 = [](float* dst, const float4& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; };
-        for (int idx = tid; idx < N * kH1 / 4; idx += 256) put4(&L.W1[(idx / (kH1 / 4)) * kLD1 + 4 * (idx % (kH1 / 4))], W1v[idx]);
-        for (int idx = tid; idx < kH1 * kH2 / 4; idx += 256) put4(&L.W2[(idx / (kH2 / 4)) * kLD2 + 4 * (idx % (kH2 / 4))], W2v[idx]);
-        for (int idx = tid; idx < kH2 * kH3 / 4; idx += 256) put4(&L.W3[(idx / (kH3 / 4)) * kLD3 + 4 * (idx % (kH3 / 4))], W3v[idx]);
+        // every load of a thread is issued before its first LDS write (16 + 8 + 1..2 float4 per thread: ~100 registers that nothing else needs
+        // yet): with the loads issued a few at a time the fill took 2.9 us of the 24.6 us a workgroup spends on an 8-tile minibatch (wall-clock
+        // stamps, tools/dev/coop_stamps.py)
+        constexpr int Q1 = (N * kH1 / 4 + 255) / 256, Q2 = kH1 * kH2 / 4 / 256, Q3 = kH2 * kH3 / 4 / 256;
+        static_assert(kH1 * kH2 / 4 % 256 == 0 && kH2 * kH3 / 4 % 256 == 0, "");
+        float4 v1[Q1], v2[Q2], v3[Q3];
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) v2[q] = W2v[tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < Q3; ++q) v3[q] = W3v[tid + 256 * q];
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) v1[q] = tid + 256 * q < N * kH1 / 4 ? W1v[tid + 256 * q] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            const int idx = tid + 256 * q;
+            if (idx < N * kH1 / 4) put4(&L.W1[(idx / (kH1 / 4)) * kLD1 + 4 * (idx % (kH1 / 4))], v1[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) { const int idx = tid + 256 * q; put4(&L.W2[(idx / (kH2 / 4)) * kLD2 + 4 * (idx % (kH2 / 4))], v2[q]); }
+#pragma unroll
+        for (int q = 0; q < Q3; ++q) { const int idx = tid + 256 * q; put4(&L.W3[(idx / (kH3 / 4)) * kLD3 + 4 * (idx % (kH3 / 4))], v3[q]); }
     }
+#endif
     if (tid < 32) L.zeros[tid] = 0.f;
     if (tid < 128) L.sums[tid >> 5][tid & 31] = 0.0;
     for (int idx = tid; idx < kExFloats; idx += 256) L.E[2][idx] = 0.f;   // (the first tile's chain 2 reads "the previous tile's a1b" from here)
     for (int idx = tid; idx < 32 * NP; idx += 256) { L.zs[idx] = 0.f; L.gzbs[idx] = 0.f; }
     __syncthreads();
+    COOP_STAMP();                                                                       // 1: LDS filled
     const S& sys = sys_s;
     const MlpP<N>& p = p_s;
     const TaskP<float, N, M>& tk = tk_s;
@@ -578,6 +611,7 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
         }
 #endif
     }
+    COOP_STAMP();                                                                       // tile loop and dW1 tail done
     // ---- partial sums of this workgroup (added in workgroup order by k_train_coop_reduce: deterministic, no float atomics) ------------------
     float* out = partial + (int64_t)blockIdx.x * kCoopBlocks * 1024;
     auto put = [&](int blk, const f32x16& a) {
@@ -615,6 +649,10 @@ __global__ __launch_bounds__(256, 1) void k_train_coop(S sys_k, MlpP<S::N> p_k, 
             rec[0] = acc_h; rec[1] = acc_t; rec[2] = acc_ni; rec[3] = acc_nd;
         }
     }
+    COOP_STAMP();                                                                       // partial sums stored
+#ifdef HJBX_COOP_STAMPS
+    if (stamp_on) stamp_buf[63] = (unsigned long long)stamp_idx;
+#endif
 }
 
 // Sum of `count` records base[g stride] in a FIXED order: eight interleaved running sums (eight loads in flight: these reductions are latency
