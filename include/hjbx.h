@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HJBX_VERSION 110 /* major*100 + minor */
+#define HJBX_VERSION 111 /* major*100 + minor */
 #define HJBX_MAX_N 10    /* largest state dimension (NearHoverQuadcopter) */
 #define HJBX_MAX_M 3     /* largest control dimension */
 
@@ -372,9 +372,20 @@ int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, doubl
  * adam->param[] must be the network's W1, W2, W3.  workspace: hjbx_value_loss_adam_workspace_bytes(B) bytes, 256-byte aligned, need not be
  * initialised.  (A data-parallel step needs the flat buffer for its all-reduce: hjbx_value_loss_grad_f32, all-reduce, hjbx_mix_adam_f32.) */
 size_t hjbx_value_loss_adam_workspace_bytes(int64_t B);
+/* optional last duty of that call: assemble the NEXT update's minibatch (what hjbx_replay_gather_f32 would do for index step_counter + 1, same
+ * arguments and bounds behaviour) inside the epilogue kernel, so that a captured fit-phase update is two launches.  reg_out may be the buffer
+ * reg_dev points to (it is written after every read of this update). */
+typedef struct hjbx_next_minibatch {
+    const float* buf_x; const float* buf_cost; const float* buf_done;
+    int64_t capacity; int n;
+    const int32_t* perm; int64_t perm_len;
+    const float* reg_table; int64_t table_len;
+    int64_t batch;
+    float* xs; float* costs; float* dones; float* reg_out;
+} hjbx_next_minibatch;
 int hjbx_value_loss_adam_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
                              const float* done, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
-                             float* loss_accum, int32_t* step_counter, void* workspace, int64_t B, void* stream);
+                             float* loss_accum, int32_t* step_counter, const hjbx_next_minibatch* next, void* workspace, int64_t B, void* stream);
 
 /* The minibatch of one update, assembled on the device: DataLoader(batch_size, shuffle=True, drop_last=True) + np_collate of the reference
  * (vhjb.py:151-154, 314; utils/utils.py:7-14) for a device-resident replay buffer (buf_x (capacity, n), buf_cost, buf_done (capacity,)):

@@ -53,6 +53,13 @@ class HjbxAdamState(C.Structure):
                 ("step", C.c_void_p * 3), ("ticket", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
 
 
+class HjbxNextMinibatch(C.Structure):
+    """struct hjbx_next_minibatch"""
+    _fields_ = [("buf_x", C.c_void_p), ("buf_cost", C.c_void_p), ("buf_done", C.c_void_p), ("capacity", C.c_int64), ("n", C.c_int),
+                ("perm", C.c_void_p), ("perm_len", C.c_int64), ("reg_table", C.c_void_p), ("table_len", C.c_int64), ("batch", C.c_int64),
+                ("xs", C.c_void_p), ("costs", C.c_void_p), ("dones", C.c_void_p), ("reg_out", C.c_void_p)]
+
+
 class HjbxTask(C.Structure):
     """struct hjbx_task"""
     _fields_ = [
@@ -269,7 +276,7 @@ def lib() -> C.CDLL:
         L.hjbx_value_loss_adam_workspace_bytes.argtypes = [_I64]
         L.hjbx_value_loss_adam_f32.restype = C.c_int
         L.hjbx_value_loss_adam_f32.argtypes = [_VP, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _DBL, _DBL, C.POINTER(HjbxAdamState), _VP, _VP,
-                                               _VP, _VP, _I64, _VP]
+                                               _VP, C.POINTER(HjbxNextMinibatch), _VP, _I64, _VP]
         L.hjbx_replay_gather_f32.restype = C.c_int
         L.hjbx_replay_gather_f32.argtypes = [_VP, _VP, _VP, _I64, _I32, _VP, _I64, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _VP, _VP]
         for name, sig in _typed_signatures().items():

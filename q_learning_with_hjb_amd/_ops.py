@@ -317,10 +317,30 @@ def _reg_args(regularization):
     return None, float(regularization)
 
 
+def next_minibatch(buf_x, buf_cost, buf_done, perm, reg_table, xs, costs, dones, reg_out):
+    """struct hjbx_next_minibatch for value_loss_adam: what replay_gather would be called with for the update after this one."""
+    batch, n = xs.shape
+    _chk(buf_x, "buf_x", (buf_x.shape[0], n), torch.float32)
+    _chk(buf_cost, "buf_cost", (buf_x.shape[0],), torch.float32)
+    _chk(buf_done, "buf_done", (buf_x.shape[0],), torch.float32)
+    _chk(perm, "perm", (perm.shape[0],), torch.int32)
+    _chk(costs, "costs", (batch,), torch.float32)
+    _chk(dones, "dones", (batch,), torch.float32)
+    _chk(reg_out, "reg_out", (), torch.float32)
+    _chk(reg_table, "reg_table", (reg_table.shape[0],), torch.float32)
+    nx = _abi.HjbxNextMinibatch()
+    nx.buf_x, nx.buf_cost, nx.buf_done, nx.capacity, nx.n = buf_x.data_ptr(), buf_cost.data_ptr(), buf_done.data_ptr(), buf_x.shape[0], n
+    nx.perm, nx.perm_len, nx.reg_table, nx.table_len, nx.batch = perm.data_ptr(), perm.shape[0], reg_table.data_ptr(), reg_table.shape[0], batch
+    nx.xs, nx.costs, nx.dones, nx.reg_out = xs.data_ptr(), costs.data_ptr(), dones.data_ptr(), reg_out.data_ptr()
+    nx._keep = (buf_x, buf_cost, buf_done, perm, reg_table, xs, costs, dones, reg_out)       # the struct holds raw pointers
+    return nx
+
+
 def value_loss_adam(sys, task, mlp_desc, x, cost, done, mode, regularization, eps, params, exp_avgs, exp_avg_sqs, steps, ticket, lr, beta1, beta2,
-                    adam_eps, loss_accum=None, step_counter=None):
+                    adam_eps, loss_accum=None, step_counter=None, next_mb=None):
     """hjbx_value_loss_adam_f32: params_update in one call (gradient, counts, mix, losses, Adam) for a single process; the flat gradient buffer is
-    not materialised on the default path.  -> losses (3,) = [total, hjb, termination]"""
+    not materialised on the default path.  next_mb (next_minibatch(...)): the epilogue also assembles the minibatch of update step_counter + 1.
+    -> losses (3,) = [total, hjb, termination]"""
     B = x.shape[0]
     _chk(x, "x", (B, sys.n), torch.float32)
     _chk(cost, "cost", (B,), torch.float32)
@@ -334,7 +354,7 @@ def value_loss_adam(sys, task, mlp_desc, x, cost, done, mode, regularization, ep
         _chk(step_counter, "step_counter", (1,), torch.int32)
     ws = _train_workspace(x.device, lib().hjbx_value_loss_adam_workspace_bytes(B))
     check(lib().hjbx_value_loss_adam_f32(sys.ptr, ref(task), ref(mlp_desc), int(mode), _p(x), _p(cost), _p(done), reg_dev, reg, float(eps), C.byref(st), _p(losses),
-                                         _p(loss_accum), _p(step_counter), _p(ws), B, _stream()))
+                                         _p(loss_accum), _p(step_counter), None if next_mb is None else C.byref(next_mb), _p(ws), B, _stream()))
     return losses
 
 

@@ -564,22 +564,27 @@ class VHJBController(Controller):
     def _adam_state(self, params):
         return adam_state(self.optimizer, params)
 
-    def _update_core(self, xs, dones, costs, regularization, loss_accum=None, step_counter=None):
+    def _one_call_update(self) -> bool:
+        """params_update as ONE C-ABI call (hjbx_value_loss_adam_f32): the library's Adam, one process, value_loss_gradient not overridden"""
+        return (self.fused_param_grad and self._native_adam and not self._distributed()
+                and type(self).value_loss_gradient is VHJBController.value_loss_gradient and "value_loss_gradient" not in self.__dict__)
+
+    def _update_core(self, xs, dones, costs, regularization, loss_accum=None, step_counter=None, next_mb=None):
         """`regularization` is a float, or a 0-dim device tensor when the step is being captured into a graph.  loss_accum / step_counter
         (fused path only): device-side `total_losses += ...` and `update_counter += 1` of train (vhjb.py:320-323)."""
         model_params = list(self.value_function_approximator.parameters())
         if self.fused_param_grad:
             # one C-ABI call: [d sum(hjb)/dW | d sum(termination)/dW | sum hjb, sum termination, #interior, #done] -- exactly the buffer
             # the data-parallel step all-reduces once; then the division by the (global) counts and the mix (vhjb.py:241, 253, 284)
-            if (self._native_adam and not self._distributed() and type(self).value_loss_gradient is VHJBController.value_loss_gradient
-                    and "value_loss_gradient" not in self.__dict__):
+            if self._one_call_update():
                 # one process: gradient, counts, mix, the three losses and optax.adam's step (vhjb.py:120, 262-263) in ONE C-ABI call of two
-                # launches -- the flat buffer is not even materialised (hjbx_value_loss_adam_f32), on the optimiser's own state tensors
+                # launches -- the flat buffer is not even materialised (hjbx_value_loss_adam_f32), on the optimiser's own state tensors; in the fit
+                # graph its epilogue also gathers the next update's minibatch (next_mb)
                 m, v, step = self._adam_state(model_params)
                 g = self.optimizer.param_groups[0]
                 losses = _ops.value_loss_adam(self.dynamics.system, self._task, self.value_function_approximator.descriptor(), xs, costs, dones,
                                               self.residual_mode, regularization, self.epsilon, [p.data for p in model_params], m, v, step,
-                                              self._adam_ticket, g["lr"], g["betas"][0], g["betas"][1], g["eps"], loss_accum, step_counter)
+                                              self._adam_ticket, g["lr"], g["betas"][0], g["betas"][1], g["eps"], loss_accum, step_counter, next_mb)
                 return losses[0], losses[1], losses[2]
             flat = self.value_loss_gradient(xs, dones, costs)
             if self._native_adam:
@@ -665,6 +670,7 @@ class VHJBController(Controller):
         fg.reg_table[:nb].copy_(table, non_blocking=False)
         fg.step.zero_()
         fg.loss_accum.zero_()
+        fg.begin_epoch()
         fg.replay(nb)
         sums = fg.loss_accum.cpu().tolist()
         self.update_counter += nb
@@ -829,7 +835,8 @@ def capture_step(optimizer, params, step_fn, dev, before_each=None):
 
 class FitGraph:
     """The optimiser step of the fit phase with its minibatch selection inside the graph (VHJBController._fit_epoch_graphed):
-    hjbx_replay_gather_f32 -> hjbx_value_loss_adam_f32 (gradient kernel + one reduce / mix / Adam epilogue).  Static buffers: perm (replay capacity, int32), reg_table (one
+    hjbx_value_loss_adam_f32 (gradient kernel + one epilogue: reduce / mix / Adam / gather of the NEXT minibatch; the first minibatch of an epoch
+    by hjbx_replay_gather_f32).  Static buffers: perm (replay capacity, int32), reg_table (one
     entry per update of an epoch), step (device update counter within the epoch), loss_accum (3 running loss sums).  Because nothing on the
     host changes between two updates, UNROLL consecutive updates are also captured as one graph: a launch of that graph pays the
     graph-to-graph gap (about 8 us on MI355X) once per UNROLL updates."""
@@ -852,13 +859,27 @@ class FitGraph:
         self.reg = torch.zeros((), dtype=torch.float32, device=dev)
         self._ctl_ref = weakref.ref(ctl)      # (no reference cycle: the graphs die with the controller, not at some later garbage collection)
         self._streams, self._graphs = [], {}
+        # two kernels per update when the one-call update is in use: its epilogue gathers the next minibatch
+        self.fused_next = ctl._one_call_update()
+        self._next_mb = _ops.next_minibatch(rb.x, rb.cost, rb.done, self.perm, self.reg_table, self.xs, self.costs, self.dones, self.reg) if self.fused_next else None
         self._capture(1)
+
+    def _gather(self):
+        rb = self._ctl_ref().replay_buffer
+        _ops.replay_gather(rb.x, rb.cost, rb.done, self.perm, self.step, self.reg_table, self.xs, self.costs, self.dones, self.reg)
 
     def _one_update(self):
         ctl = self._ctl_ref()
-        rb = ctl.replay_buffer
-        _ops.replay_gather(rb.x, rb.cost, rb.done, self.perm, self.step, self.reg_table, self.xs, self.costs, self.dones, self.reg)
+        if self.fused_next:
+            # the previous update's epilogue (or _gather at the start of the epoch) has assembled this minibatch; this update's assembles the next
+            return ctl._update_core(self.xs, self.dones, self.costs, self.reg, loss_accum=self.loss_accum, step_counter=self.step, next_mb=self._next_mb)
+        self._gather()
         return ctl._update_core(self.xs, self.dones, self.costs, self.reg, loss_accum=self.loss_accum, step_counter=self.step)
+
+    def begin_epoch(self):
+        """(after perm and reg_table are filled and step is zeroed)"""
+        if self.fused_next:
+            self._gather()
 
     def _capture(self, count: int):
         ctl = self._ctl_ref()
@@ -869,10 +890,14 @@ class FitGraph:
             return out
 
         saved = (self.step.clone(), self.loss_accum.clone())
-        stream, graph, out = capture_step(ctl.optimizer, list(ctl.value_function_approximator.parameters()), step_fn, ctl.device,
-                                          before_each=self.step.zero_)
+        def before_each():
+            self.step.zero_()
+            self.begin_epoch()
+
+        stream, graph, out = capture_step(ctl.optimizer, list(ctl.value_function_approximator.parameters()), step_fn, ctl.device, before_each=before_each)
         self.step.copy_(saved[0])
         self.loss_accum.copy_(saved[1])
+        self.begin_epoch()                     # (the warm-up runs left another minibatch in the input buffers: gather the current one again)
         self._streams.append(stream)
         self._graphs[count] = (graph, out)
 

@@ -19,8 +19,37 @@ struct MixArgs {
     float* losses; float* loss_accum; int32_t* step_counter;
 };
 
-// the epilogue of the fused update (hjbx_value_loss_adam_f32): reduction of the per-workgroup partial sums, mix and Adam in one kernel
-struct FuseArgs { AdamArgs a; MixArgs mx; };
+// The minibatch of an update, assembled on the device (hjbx_replay_gather_f32; DataLoader(shuffle, drop_last) + np_collate, vhjb.py:151-154, 314):
+// rows perm[k batch .. (k + 1) batch) of the replay buffer.  enabled == 0: nothing to gather.
+struct GatherArgs {
+    const float* bx; const float* bc; const float* bd; int64_t capacity; int n;
+    const int32_t* perm; int64_t perm_len; const float* reg_table; int64_t table_len; int64_t batch;
+    float* ox; float* oc; float* od; float* oreg;
+    int enabled;
+};
+// A counter that has run past the epoch (or a permutation entry outside the buffer) must not become an out-of-bounds access -- a GPU fault takes
+// the whole node down: such a launch gathers nothing and leaves the regularisation weight at NaN, so the step it feeds fails visibly.
+__device__ __forceinline__ bool gather_in_range(const GatherArgs& g, int64_t k) {
+    return k >= 0 && (k + 1) * g.batch <= g.perm_len && (!g.reg_table || k < g.table_len);
+}
+__device__ __forceinline__ void gather_elements(const GatherArgs& g, int64_t k, int64_t first, int64_t stride) {   // element t = (sample, column)
+    if (!gather_in_range(g, k)) return;
+    for (int64_t t = first; t < g.batch * g.n; t += stride) {
+        const int64_t smp = t / g.n;
+        const int c = (int)(t - smp * g.n);
+        const int64_t row = g.perm[k * g.batch + smp];
+        if (row < 0 || row >= g.capacity) continue;
+        g.ox[t] = g.bx[row * g.n + c];
+        if (c == 0) { g.oc[smp] = g.bc[row]; g.od[smp] = g.bd[row]; }
+    }
+}
+__device__ __forceinline__ void gather_reg(const GatherArgs& g, int64_t k) {
+    if (g.oreg && g.reg_table) g.oreg[0] = gather_in_range(g, k) ? g.reg_table[k] : __builtin_nanf("");
+}
+
+// the epilogue of the fused update (hjbx_value_loss_adam_f32): reduction of the per-workgroup partial sums, mix and Adam in one kernel -- and,
+// optionally, the NEXT update's minibatch (index step_counter + 1), so that a fit-phase graph is two kernels per update
+struct FuseArgs { AdamArgs a; MixArgs mx; GatherArgs next; };
 
 // host: validate an hjbx_adam_state and turn it into kernel arguments (`who` prefixes the error message)
 inline int adam_args_from(const hjbx_adam_state* adam, const char* who, AdamArgs& a) {
@@ -79,8 +108,10 @@ __device__ __forceinline__ void adam_element(const AdamArgs& a, const AdamCoef& 
 
 // After a workgroup's elements (contains a __syncthreads): the last workgroup to arrive writes the new step count, the losses and the counters.
 // h, tl: hjb and termination loss (sums already divided by their counts); reg: the regularisation weight of this update.
-__device__ __forceinline__ void adam_finish(const AdamArgs& a, const AdamCoef& c, const MixArgs& mx, float h, float tl, float reg) {
+// -> true for thread 0 of that last workgroup (for work that must follow every other workgroup's reads)
+__device__ __forceinline__ bool adam_finish(const AdamArgs& a, const AdamCoef& c, const MixArgs& mx, float h, float tl, float reg) {
     __syncthreads();
+    bool last = false;
     if (threadIdx.x == 0) {
         const unsigned int old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == gridDim.x - 1) {   // all workgroups have read the old step count
@@ -89,6 +120,8 @@ __device__ __forceinline__ void adam_finish(const AdamArgs& a, const AdamCoef& c
             if (mx.losses) { mx.losses[0] = h + reg * tl; mx.losses[1] = h; mx.losses[2] = tl; }
             if (mx.loss_accum) { mx.loss_accum[0] += h + reg * tl; mx.loss_accum[1] += h; mx.loss_accum[2] += tl; }   // total_losses += ... (vhjb.py:320-322)
             if (mx.step_counter) mx.step_counter[0] += 1;                                                              // update_counter += 1 (vhjb.py:323)
+            last = true;
         }
     }
+    return last;
 }

@@ -42,24 +42,11 @@ extern "C" int hjbx_mix_gradients_f32(const float* flat, int64_t n_params, const
 // device-resident replay buffer: minibatch k of an epoch is rows perm[k batch .. (k + 1) batch) of the buffer.  k is read from DEVICE memory
 // (the counter hjbx_mix_gradients_f32 increments) and so is the regularisation weight of that update (a per-epoch table of the schedule,
 // vhjb.py:323-324): a captured hipGraph of gather -> gradient -> mix -> Adam replays with NO host-side work between two updates.
-__global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__ bx, const float* __restrict__ bc, const float* __restrict__ bd, int n,
-                                                      const int32_t* __restrict__ perm, int64_t perm_len, int64_t capacity, const int32_t* __restrict__ step,
-                                                      const float* __restrict__ reg_table, int64_t table_len, int64_t batch, float* __restrict__ ox,
-                                                      float* __restrict__ oc, float* __restrict__ od, float* __restrict__ oreg) {
-    // A counter that has run past the epoch (or a permutation entry outside the buffer) must not become an out-of-bounds access -- a GPU
-    // fault takes the whole node down: such a launch gathers nothing and leaves the regularisation weight at NaN, so the step it feeds
-    // fails visibly (NaN losses) instead of silently.
+__global__ __launch_bounds__(256) void k_replay_gather(GatherArgs g, const int32_t* __restrict__ step) {
     const int64_t k = step ? (int64_t)step[0] : 0;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool in_range = k >= 0 && (k + 1) * batch <= perm_len && (!reg_table || k < table_len);
-    if (t == 0 && oreg && reg_table) oreg[0] = in_range ? reg_table[k] : __builtin_nanf("");
-    if (!in_range || t >= batch * n) return;
-    const int64_t smp = t / n;
-    const int c = (int)(t - smp * n);
-    const int64_t row = perm[k * batch + smp];
-    if (row < 0 || row >= capacity) return;
-    ox[t] = bx[row * n + c];
-    if (c == 0) { oc[smp] = bc[row]; od[smp] = bd[row]; }
+    if (t == 0) gather_reg(g, k);
+    gather_elements(g, k, t, (int64_t)gridDim.x * 256);
 }
 
 extern "C" int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost, const float* buf_done, int64_t capacity, int n, const int32_t* perm,
@@ -73,8 +60,8 @@ extern "C" int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost,
     if (batch == 0) return HJBX_OK;
     if (batch > perm_len) return hjbx_set_error(HJBX_EINVAL, "hjbx_replay_gather_f32: a minibatch of %lld rows from a permutation of %lld", (long long)batch, (long long)perm_len);
     const int64_t nthreads = batch * n;
-    hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, buf_x, buf_cost, buf_done, n, perm, perm_len,
-                       capacity, step_dev, reg_table, table_len, batch, xs, costs, dones, reg_out);
+    const GatherArgs g{buf_x, buf_cost, buf_done, capacity, n, perm, perm_len, reg_table, table_len, batch, xs, costs, dones, reg_out, 1};
+    hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, step_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hjbx_set_error(HJBX_EHIP, "hjbx_replay_gather_f32: %s", hipGetErrorString(e));
     return HJBX_OK;

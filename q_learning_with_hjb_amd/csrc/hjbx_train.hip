@@ -699,10 +699,14 @@ extern "C" size_t hjbx_value_loss_adam_workspace_bytes(int64_t B) {
 
 extern "C" int hjbx_mix_adam_f32(const float* flat, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
                                  float* loss_accum, int32_t* step_counter, void* stream);
+extern "C" int hjbx_replay_gather_f32(const float* buf_x, const float* buf_cost, const float* buf_done, int64_t capacity, int n, const int32_t* perm,
+                                      int64_t perm_len, const int32_t* step_dev, const float* reg_table, int64_t table_len, int64_t batch, float* xs,
+                                      float* costs, float* dones, float* reg_out, void* stream);
 
 extern "C" int hjbx_value_loss_adam_f32(const hjbx_system* sys, const hjbx_task* task, const hjbx_mlp* mlp, int mode, const float* x, const float* cost,
                                         const float* done, const float* reg_dev, double reg, double eps, const hjbx_adam_state* adam, float* losses,
-                                        float* loss_accum, int32_t* step_counter, void* workspace, int64_t B, void* stream) {
+                                        float* loss_accum, int32_t* step_counter, const hjbx_next_minibatch* next, void* workspace, int64_t B,
+                                        void* stream) {
     if (int rc = check_vlg("hjbx_value_loss_adam_f32", sys, task, mlp, mode, x, cost, done, workspace, B)) return rc;
     if (B == 0) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: empty minibatch");
     FuseArgs f{};
@@ -712,8 +716,20 @@ extern "C" int hjbx_value_loss_adam_f32(const hjbx_system* sys, const hjbx_task*
     const int64_t P = (int64_t)sys->n * kH1 + (int64_t)kH1 * kH2 + (int64_t)kH2 * kH3;
     if (f.a.P != P) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the Adam state holds %lld parameters, the network %lld", (long long)f.a.P, (long long)P);
     f.mx = MixArgs{reg_dev, (float)reg, (float)eps, losses, loss_accum, step_counter};
+    if (next) {
+        if (!step_counter) return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the next minibatch is numbered by step_counter, which is NULL");
+        if (!next->buf_x || !next->buf_cost || !next->buf_done || !next->perm || !next->xs || !next->costs || !next->dones)
+            return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: next minibatch: NULL buffer");
+        if (next->n != sys->n || next->batch < 1 || next->capacity < 1 || next->perm_len < next->batch || next->table_len < 0 || (next->reg_out && !next->reg_table))
+            return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: next minibatch: bad n, batch, capacity, lengths, or reg_out without reg_table");
+        f.next = GatherArgs{next->buf_x, next->buf_cost, next->buf_done, next->capacity, next->n, next->perm, next->perm_len, next->reg_table, next->table_len,
+                            next->batch, next->xs, next->costs, next->dones, next->reg_out, 1};
+    }
     if (!use_two_kernels(mlp->activation)) return hjbx_train_coop(sys, task, mlp, mode, x, cost, done, nullptr, workspace, B, stream, &f);
     float* flat = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((hjbx_value_loss_grad_workspace_bytes(B) + 255) & ~(size_t)255));
     if (int rc = run_pair(sys, task, mlp, mode, x, cost, done, flat, workspace, B, stream)) return rc;
-    return hjbx_mix_adam_f32(flat, reg_dev, reg, eps, adam, losses, loss_accum, step_counter, stream);
+    if (int rc = hjbx_mix_adam_f32(flat, reg_dev, reg, eps, adam, losses, loss_accum, step_counter, stream)) return rc;
+    if (!next) return HJBX_OK;     // (the counter has been incremented by the launch above: the gather below reads the next index from it)
+    return hjbx_replay_gather_f32(next->buf_x, next->buf_cost, next->buf_done, next->capacity, next->n, next->perm, next->perm_len, step_counter, next->reg_table,
+                                  next->table_len, next->batch, next->xs, next->costs, next->dones, next->reg_out, stream);
 }

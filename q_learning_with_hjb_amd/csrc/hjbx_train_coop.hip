@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void k_train_coop_reduce(const float* __restri
 // reference's minibatch this removes one launch-bound kernel from the update (gather -> gradient -> this).
 template <int N>
 __global__ __launch_bounds__(256) void k_train_coop_update(const float* __restrict__ partial, const float* __restrict__ partial_w1, int nparts, int psplit,
-                                                          const double* __restrict__ sums_rec, AdamArgs a, MixArgs mx) {
+                                                          const double* __restrict__ sums_rec, AdamArgs a, MixArgs mx, GatherArgs next) {
     __shared__ float sc[2];
     __shared__ double tot[4];
     __shared__ double rec[4 * kCoopMaxGrid];          // the loss-sum records of the workgroups (at most one workgroup per CU)
@@ -776,7 +776,11 @@ __global__ __launch_bounds__(256) void k_train_coop_update(const float* __restri
     const float ih = 1.0f / ((float)tot[2] + mx.eps), it = 1.0f / ((float)tot[3] + mx.eps);
     const float wt = reg * it;
     if (which >= 0) adam_element(a, c, which, j, sh * ih + st * wt);
-    adam_finish(a, c, mx, (float)tot[0] * ih, (float)tot[1] * it, reg);
+    // the NEXT update's minibatch (index = this update's + 1; every workgroup reads the counter before the last one increments it below): its
+    // rows by all threads, its regularisation weight by the last workgroup -- the buffer may be the one this launch read `reg` from
+    const int64_t k_next = next.enabled && mx.step_counter ? (int64_t)mx.step_counter[0] + 1 : 0;
+    if (next.enabled) gather_elements(next, k_next, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+    if (adam_finish(a, c, mx, (float)tot[0] * ih, (float)tot[1] * it, reg) && next.enabled) gather_reg(next, k_next);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------------
@@ -843,7 +847,7 @@ static int launch_coop(const hjbx_system* sysh, S sys, const hjbx_task* task, co
                 return hjbx_set_error(HJBX_EINVAL, "hjbx_value_loss_adam_f32: the Adam state's tensors must be W1 (%d x 128), W2 (128 x 128), W3 (128 x 64)", N);
             if (w.grid > kCoopMaxGrid) return hjbx_set_error(HJBX_EUNSUPPORTED, "hjbx_value_loss_adam_f32: %d workgroups (more than %d CUs?)", w.grid, kCoopMaxGrid);
             const int nthreads = kCoopSet * 1024 + N * 128;
-            hipLaunchKernelGGL((k_train_coop_update<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, w.psplit, sums, fuse->a, fuse->mx);
+            hipLaunchKernelGGL((k_train_coop_update<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, w.psplit, sums, fuse->a, fuse->mx, fuse->next);
         } else {
             const int nthreads = kCoopBlocks * 1024 + 2 * N * 128 + 4;
             hipLaunchKernelGGL((k_train_coop_reduce<N>), dim3((nthreads + 255) / 256), dim3(256), 0, s, partial, partial_w1, w.grid, w.psplit, sums, flat);

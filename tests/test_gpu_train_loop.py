@@ -268,3 +268,42 @@ def test_fit_phase_entry_points_refuse_bad_arguments():
     with pytest.raises(ValueError):
         _ops.mix_adam(flat[:-1].contiguous(), 0.1, 1e-7, w, m, v, steps, ticket, 1e-3, 0.9, 0.999, 1e-8)   # flat does not hold 2 P + 4 floats
     assert L.hjbx_mix_gradients_f32(None, 6, None, 0.0, 1e-7, p(flat), None, None, None, None) == _abi.EINVAL
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_update_epilogue_assembles_the_next_minibatch(kernel):
+    """hjbx_value_loss_adam_f32 with `next`: after update k the input buffers hold minibatch k + 1 and the regularisation scalar entry k + 1 of
+    the table -- exactly what hjbx_replay_gather_f32 produces for the incremented counter -- in the cooperative implementation (inside the
+    epilogue kernel) and in the two-kernel one (a gather launch after the mix); past the end of the permutation nothing is gathered and the
+    weight becomes NaN."""
+    from q_learning_with_hjb_amd import _abi, _ops
+    from q_learning_with_hjb_amd.controller.vhjb import adam_state
+    prev = _abi.set_option(_abi.OPT_TRAIN_KERNEL, kernel)
+    try:
+        d = make_dynamics("cartpole")
+        ctl = VHJBController(d, make_vhjb_config("cartpole", maximum_buffer_size=400), dtype=torch.float32, graph_updates=False)
+        rb, n, batch = ctl.replay_buffer, d.state_dim, 64
+        g = torch.Generator(device="cuda").manual_seed(1)
+        rb.x.copy_(torch.rand(rb.x.shape, generator=g, device="cuda") * 0.2 + torch.as_tensor(np.asarray(ctl.xf, np.float32), device="cuda"))
+        rb.cost.copy_(torch.rand(rb.cost.shape, generator=g, device="cuda"))
+        rb.done.copy_((torch.rand(rb.done.shape, generator=g, device="cuda") < 0.3).float())
+        perm = torch.randperm(3 * batch, generator=g, device="cuda").to(torch.int32)       # three minibatches
+        table = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+        xs, cs, ds = (torch.empty((batch, n), device="cuda"), torch.empty(batch, device="cuda"), torch.empty(batch, device="cuda"))
+        reg, step, acc = torch.zeros((), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(3, device="cuda")
+        _ops.replay_gather(rb.x, rb.cost, rb.done, perm, step, table, xs, cs, ds, reg)
+        nx = _ops.next_minibatch(rb.x, rb.cost, rb.done, perm, table, xs, cs, ds, reg)
+        vf = ctl.value_function_approximator
+        params = list(vf.parameters())
+        m, v, steps = adam_state(ctl.optimizer, params)
+        for k in range(3):
+            idx = perm[k * batch:(k + 1) * batch].long()
+            assert torch.equal(xs, rb.x[idx]) and torch.equal(cs, rb.cost[idx]) and torch.equal(ds, rb.done[idx]) and abs(float(reg) - 0.1 * (k + 1)) < 1e-7
+            before = xs.clone()
+            _ops.value_loss_adam(d.system, ctl._task, vf.descriptor(), xs, cs, ds, ctl.residual_mode, reg, ctl.epsilon, [p.data for p in params], m, v, steps,
+                                 ctl._adam_ticket, 1e-3, 0.9, 0.999, 1e-8, acc, step, nx)
+            assert int(step) == k + 1
+        assert torch.equal(xs, before) and torch.isnan(reg)          # there is no fourth minibatch: nothing gathered, the weight poisoned
+        assert all(float(t) == 3.0 for t in steps) and torch.isfinite(acc).all()
+    finally:
+        _abi.set_option(_abi.OPT_TRAIN_KERNEL, prev)
